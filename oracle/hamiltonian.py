@@ -1,0 +1,126 @@
+"""Oracle (test infrastructure): local energy = kinetic (Laplacian) + Ewald.
+
+Restates /root/reference/DeepSolid/hamiltonian.py with torch.func autodiff in
+float64.  `for` is the reference default (hamiltonian.py:45-70): a sequential
+loop of 3N forward-over-reverse Hessian-vector products for Re f and Im f.
+`forward_laplacian` is NOT in the reference: it restates the algorithm the HIP
+kernels use (value / gradient / Laplacian propagated forward) so that large
+batches can be checked in seconds; it is itself checked against `for`.
+"""
+import torch
+from torch.func import grad, hessian, jvp, vmap
+
+from . import ewaldsum
+
+
+def _re(f):
+    return lambda p, y: f(p, y).real
+
+
+def _im(f):
+    return lambda p, y: f(p, y).imag
+
+
+# hamiltonian.py:45-70
+def local_kinetic_energy_real_imag(f):
+    def _lapl_over_f(params, x):
+        ne = x.shape[-1]
+        eye = torch.eye(ne, dtype=x.dtype)
+        g_re = lambda y: grad(_re(f), argnums=1)(params, y)
+        g_im = lambda y: grad(_im(f), argnums=1)(params, y)
+        kr = torch.zeros((), dtype=x.dtype)
+        ki = torch.zeros((), dtype=x.dtype)
+        for i in range(ne):                      # jax.lax.fori_loop(0, ne, ...)
+            p_re, t_re = jvp(g_re, (x,), (eye[i],))
+            p_im, t_im = jvp(g_im, (x,), (eye[i],))
+            kr = kr + t_re[i] + p_re[i] ** 2 - p_im[i] ** 2
+            ki = ki + t_im[i] + 2 * p_re[i] * p_im[i]
+        return [-0.5 * kr, -0.5 * ki * 1j]
+    return _lapl_over_f
+
+
+# hamiltonian.py:73-101
+def local_kinetic_energy_real_imag_dim_batch(f):
+    def _lapl_over_f(params, x):
+        ne = x.shape[-1]
+        eye = torch.eye(ne, dtype=x.dtype)
+        g_re = lambda y: grad(_re(f), argnums=1)(params, y)
+        g_im = lambda y: grad(_im(f), argnums=1)(params, y)
+
+        def body(e):
+            p_re, t_re = jvp(g_re, (x,), (e,))
+            p_im, t_im = jvp(g_im, (x,), (e,))
+            return (((t_re + p_re ** 2 - p_im ** 2) * e).sum(),
+                    ((t_im + 2 * p_re * p_im) * e).sum())
+        kr, ki = vmap(body)(eye)
+        return [-0.5 * kr.sum(), -0.5 * ki.sum() * 1j]
+    return _lapl_over_f
+
+
+# hamiltonian.py:104-124
+def local_kinetic_energy_real_imag_hessian(f):
+    def _lapl_over_f(params, x):
+        g_re = grad(_re(f), argnums=1)(params, x)
+        g_im = grad(_im(f), argnums=1)(params, x)
+        h_re = hessian(_re(f), argnums=1)(params, x)
+        h_im = hessian(_im(f), argnums=1)(params, x)
+        kr = torch.trace(h_re) + torch.sum(g_re ** 2) - torch.sum(g_im ** 2)
+        ki = torch.trace(h_im) + torch.sum(2 * g_re * g_im)
+        return [-0.5 * kr, -0.5 * ki * 1j]
+    return _lapl_over_f
+
+
+# hamiltonian.py:127-159
+def local_kinetic_energy_partition(f, partition_number=3):
+    def _lapl_over_f(params, x):
+        n = x.shape[0]
+        eye = torch.eye(n, dtype=x.dtype)
+        g_re = lambda y: grad(_re(f), argnums=1)(params, y)
+        g_im = lambda y: grad(_im(f), argnums=1)(params, y)
+        if n % partition_number:
+            raise ValueError('partition_number must divide 3*N_e')
+        prim_r, prim_i, tan_r, tan_i = [], [], [], []
+        for e in torch.chunk(eye, partition_number):          # lax.scan over array_split(eye)
+            pr, tr = vmap(lambda v: jvp(g_re, (x,), (v,)))(e)
+            pi, ti = vmap(lambda v: jvp(g_im, (x,), (v,)))(e)
+            prim_r.append(pr); prim_i.append(pi); tan_r.append(tr); tan_i.append(ti)
+        pr, pi = torch.cat(prim_r), torch.cat(prim_i)
+        tr, ti = torch.cat(tan_r), torch.cat(tan_i)
+        kr = torch.trace(tr) + torch.trace(pr ** 2) - torch.trace(pi ** 2)
+        ki = torch.trace(ti) + torch.trace(2 * pr * pi)
+        return [-0.5 * kr, -0.5j * ki]
+    return _lapl_over_f
+
+
+# hamiltonian.py:163-179
+def local_ewald_energy(simulation_cell):
+    ewald = ewaldsum.EwaldSum(simulation_cell)
+    if hasattr(simulation_cell, 'energy_nuc'):
+        ref = simulation_cell.energy_nuc()
+        if ref is not None:
+            assert abs(ref - (ewald.ion_ion + ewald.ii_const)) <= 1e-5 + 1e-8 * abs(ewald.ion_ion + ewald.ii_const)
+
+    def _local_ewald_energy(x):
+        return sum(ewald.energy(x))
+    _local_ewald_energy.ewald = ewald
+    return _local_ewald_energy
+
+
+# hamiltonian.py:194-228
+def local_energy_seperate(f, simulation_cell, mode='for', partition_number=3):
+    if mode == 'for':
+        ke_ri = local_kinetic_energy_real_imag(f)
+    elif mode == 'hessian':
+        ke_ri = local_kinetic_energy_real_imag_hessian(f)
+    elif mode == 'dim_batch':
+        ke_ri = local_kinetic_energy_real_imag_dim_batch(f)
+    elif mode == 'partition':
+        ke_ri = local_kinetic_energy_partition(f, partition_number=partition_number)
+    else:
+        raise ValueError('Unrecognized laplacian evaluation mode.')
+    ew = local_ewald_energy(simulation_cell)
+
+    def _local_energy(params, x):
+        kinetic = sum(ke_ri(params, x))
+        return kinetic, ew(x)
+    return _local_energy

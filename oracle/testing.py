@@ -1,0 +1,73 @@
+"""Oracle (test infrastructure): shared recipes for golden vectors and tests.
+
+``make_test_params`` is the single recipe for network parameters used by the
+fixture generator (tools/make_golden.py, which feeds them to the reference's
+own code) and by the tests (which feed them to the oracle and to the HIP
+path), so the parameters themselves never need to be stored: a checksum in the
+fixture guards the numpy stream.
+"""
+import numpy as np
+
+from . import network
+
+
+def make_test_params(seed, prim_atoms, nelec, net_kw, env_jitter=0.2):
+    """Reference-shaped parameter tree (network.py:60-186) from numpy
+    default_rng(seed).  The envelope pi/sigma (ones in the reference init) are
+    jittered so that their indexing is exercised by the parity tests."""
+    rng = np.random.default_rng(seed)
+    kw = {k: net_kw[k] for k in ('envelope_type', 'bias_orbitals', 'use_last_layer', 'full_det',
+                                 'hidden_dims', 'determinants', 'distance_type')}
+    params = network.init_solid_fermi_net_params(rng, prim_atoms, tuple(int(n) for n in nelec), **kw)
+    for env in params['envelope']:
+        env['pi'] = env['pi'] * (1.0 + env_jitter * rng.uniform(-1, 1, size=env['pi'].shape))
+        env['sigma'] = env['sigma'] * (1.0 + env_jitter * rng.uniform(-1, 1, size=env['sigma'].shape))
+    return params
+
+
+def params_checksum(params):
+    tot, tot2 = 0.0, 0.0
+
+    def walk(o):
+        nonlocal tot, tot2
+        if isinstance(o, dict):
+            for k in sorted(o):
+                walk(o[k])
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v)
+        else:
+            a = np.asarray(o, dtype=np.float64)
+            tot += float(a.sum())
+            tot2 += float((a * a).sum())
+    walk(params)
+    return np.asarray([tot, tot2])
+
+
+def klist_from_kpts(kpts, nelec):
+    """Occupied k list per spin: k-points filled in order, each repeated by its
+    occupation (shape of hf.SCF.klist, reference hf.py:99-104)."""
+    nk = kpts.shape[0]
+    out = []
+    for ns in nelec:
+        base, rem = divmod(int(ns), nk)
+        rows = [np.tile(k[None, :], (base + (1 if i < rem else 0), 1)) for i, k in enumerate(kpts)]
+        out.append(np.concatenate(rows, axis=0) if int(ns) > 0 else np.zeros((0, 3)))
+    return out
+
+
+# name -> recipe.  `system` keys deepsolid_amd.systems.SYSTEMS.
+CASES = {
+    'h2':            dict(system='h2', seed=11, batch=4, fd_walkers=2),
+    'lih':           dict(system='lih', seed=12, batch=6, fd_walkers=3),
+    'lih_twist':     dict(system='lih', seed=13, batch=4, twist=(0.25, 0.1, 0.4), fd_walkers=2),
+    'lih_2x1x1':     dict(system='lih', seed=14, batch=3, system_kw=dict(S=np.diag([2, 1, 1])), mcmc=False),
+    'bcc_li':        dict(system='bcc_li', seed=15, batch=4, fd_walkers=1, fd_h=5e-4, fd_tol=1e-5),
+    'bcc_li_twist':  dict(system='bcc_li', seed=16, batch=2, twist=(0.3, 0.0, 0.15), mcmc=False),
+    'graphene':      dict(system='graphene', seed=17, batch=2, mcmc=False),
+    'diamond':       dict(system='diamond', seed=18, batch=2, mcmc=False),
+    'lih_fulldet':   dict(system='lih', seed=19, batch=3, net_kw=dict(full_det=True), mcmc=False),
+    'lih_tri':       dict(system='lih', seed=20, batch=3, net_kw=dict(distance_type='tri'), mcmc=False),
+    'lih_diagenv':   dict(system='lih', seed=21, batch=3, net_kw=dict(envelope_type='diagonal'), mcmc=False),
+    'lih_fullenv':   dict(system='lih', seed=22, batch=3, net_kw=dict(envelope_type='full'), mcmc=False),
+}

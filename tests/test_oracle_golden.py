@@ -1,0 +1,133 @@
+"""Pins the CPU oracle (and the PySCF-free system builder) against vectors
+produced by executing the reference's own code (tools/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import distance as odist
+from oracle import ewaldsum as oewald
+from oracle import hamiltonian as oham
+from oracle import network as onet
+from oracle import qmc as oqmc
+from oracle.testing import CASES
+
+from common import load_case, oracle_net, tt
+
+ALL = list(CASES)
+SMALL = [c for c in ALL if c not in ('graphene', 'diamond')]
+
+
+@pytest.mark.parametrize('name', ALL)
+def test_system_builder_matches_reference_supercell(name):
+    """deepsolid_amd.supercell vs reference supercell.py run on the same primitive cell."""
+    fx, cell, klist, _, _ = load_case(name)
+    prim = cell.original_cell
+    np.testing.assert_allclose(prim.a, fx['prim_a'], atol=1e-14)
+    np.testing.assert_allclose(cell.a, fx['sim_a'], atol=1e-13)
+    np.testing.assert_allclose(cell.atom_coords(), fx['sim_atoms'], atol=1e-12)
+    np.testing.assert_array_equal(cell.atom_charges(), fx['sim_charges'])
+    assert tuple(cell.nelec) == tuple(fx['nelec'])
+    for mine, ref in ((prim.AV, fx['prim_AV']), (prim.BV, fx['prim_BV']),
+                      (cell.AV, fx['sim_AV']), (cell.BV, fx['sim_BV'])):
+        np.testing.assert_allclose(mine, ref, atol=1e-13)
+    np.testing.assert_allclose(klist[0], fx['klist_up'], atol=1e-13)
+    np.testing.assert_allclose(klist[1], fx['klist_dn'], atol=1e-13)
+
+
+@pytest.mark.parametrize('name', ALL)
+def test_forward_matches_reference(name):
+    fx, cell, klist, net_kw, params = load_case(name)
+    p = onet.params_to_torch(params)
+    net = oracle_net(cell, klist, net_kw, 'eval_phase_and_slogdet')
+    mats = oracle_net(cell, klist, net_kw, 'eval_mats')
+    atoms = tt(cell.original_cell.atom_coords())
+    for b in range(fx['x'].shape[0]):
+        x = tt(fx['x'][b])
+        ph, ls = net.apply(p, x)
+        assert abs(float(ls) - fx['logabs'][b]) < 1e-10
+        assert abs(complex(ph) - fx['phase'][b]) < 1e-9
+        for s, m in enumerate(mats.apply(p, x)):
+            ref = fx[f'orbitals_{s}'][b]
+            np.testing.assert_allclose(m.numpy(), ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max())
+        ft = onet.construct_periodic_input_features(x, atoms, cell, net_kw['distance_type'])
+        for got, key in zip(ft, ('feat_ae', 'feat_ee', 'feat_r_ae', 'feat_r_ee')):
+            np.testing.assert_allclose(got.numpy(), fx[key][b], atol=1e-12)
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_2x1x1', 'bcc_li', 'graphene', 'diamond'])
+def test_ewald_matches_reference(name):
+    fx, cell, _, _, _ = load_case(name)
+    ew = oewald.EwaldSum(cell)
+    assert ew.gpoints_np.shape[0] == int(fx['ewald_ng'])
+    assert abs(ew.alpha - float(fx['ewald_alpha'])) < 1e-13
+    assert {'diagonal': 0, 'orthogonal': 1, 'general': 2}[ew.dist.mode] == int(fx['dist_mode'])
+    assert abs(ew.gweight_np.sum() - float(fx['ewald_gweight_sum'])) < 1e-12
+    assert abs(ew.ion_ion - float(fx['ewald_ion_ion'])) < 1e-10
+    assert abs(ew.ii_const - float(fx['ewald_ii_const'])) < 1e-10
+    if 'ewald_gpoints' in fx:
+        np.testing.assert_allclose(ew.gpoints_np, fx['ewald_gpoints'], atol=1e-12)
+        np.testing.assert_allclose(ew.gweight_np, fx['ewald_gweight'], rtol=1e-12)
+    for b in range(fx['x'].shape[0]):
+        got = [float(v) for v in ew.energy(tt(fx['x'][b]))]
+        np.testing.assert_allclose(got, fx['ewald'][b], atol=2e-10)
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'bcc_li', 'graphene'])
+def test_batched_wrap_matches_reference(name):
+    fx, cell, _, _, _ = load_case(name)
+    wx, wrap = odist.enforce_pbc(cell.a, tt(fx['x']))
+    np.testing.assert_allclose(wx.numpy(), fx['pbc_x'], atol=1e-11)
+    np.testing.assert_array_equal(wrap.numpy(), fx['pbc_wrap'])
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'bcc_li'])
+def test_metropolis_matches_reference(name):
+    """One mh_update and a 3-step mcmc_step, replaying the noise the reference consumed."""
+    fx, cell, klist, net_kw, params = load_case(name)
+    p = onet.params_to_torch(params)
+    net = oracle_net(cell, klist, net_kw, 'eval_slogdet')
+    f = lambda pp, xs: torch.stack([net.apply(pp, x) for x in xs])
+    xn, lpn, nacc = oqmc.mh_update(p, f, tt(fx['mh_x1']), tt(fx['mh_lp1']), 0.0, cell.a,
+                                   stddev=float(fx['mh_width']), normal=tt(fx['mh_normal']),
+                                   uniform=tt(fx['mh_uniform']))
+    np.testing.assert_allclose(xn.numpy(), fx['mh_x_new'], atol=1e-11)
+    np.testing.assert_allclose(lpn.numpy(), fx['mh_lp_new'], atol=1e-9)
+    assert float(nacc) == float(fx['mh_num_accepts'])
+    step = oqmc.make_mcmc_step(f, fx['mcmc_x0'].shape[0], cell.a, steps=int(fx['mcmc_steps']))
+    xo, pmove = step(p, tt(fx['mcmc_x0']), (tt(fx['mcmc_normals']), tt(fx['mcmc_uniforms'])),
+                     float(fx['mcmc_width']))
+    np.testing.assert_allclose(xo.numpy(), fx['mcmc_x_out'], atol=1e-11)
+    assert abs(float(pmove) - float(fx['mcmc_pmove'])) < 1e-15
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'bcc_li'])
+def test_kinetic_vs_finite_differences_of_reference_forward(name):
+    """`for`-mode restatement (hamiltonian.py:45-70) vs 4th-order FD of the
+    reference-executed eval_logdet."""
+    fx, cell, klist, net_kw, params = load_case(name)
+    p = onet.params_to_torch(params)
+    net = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    ke = oham.local_kinetic_energy_real_imag(net.apply)
+    mode = 'for' if sum(cell.nelec) <= 4 else 'hessian'
+    if mode == 'hessian':
+        ke = oham.local_kinetic_energy_real_imag_hessian(net.apply)
+    for b in range(len(fx['ke_fd'])):
+        got = complex(sum(ke(p, tt(fx['x'][b]))))
+        assert abs(got - fx['ke_fd'][b]) < float(fx['ke_fd_tol']) * max(1.0, abs(got))
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist'])
+def test_laplacian_modes_agree(name):
+    fx, cell, klist, net_kw, params = load_case(name)
+    p = onet.params_to_torch(params)
+    net = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    x = tt(fx['x'][1])
+    n3 = x.shape[0]
+    part = 3 if n3 % 3 == 0 else 2
+    vals = {m: oham.local_energy_seperate(net.apply, cell, mode=m, partition_number=part)(p, x)
+            for m in ('for', 'hessian', 'dim_batch', 'partition')}
+    ref = complex(vals['for'][0])
+    for m, (ke, ew) in vals.items():
+        assert abs(complex(ke) - ref) < 1e-10 * max(1.0, abs(ref)), m
+    with pytest.raises(ValueError):
+        oham.local_energy_seperate(net.apply, cell, mode='nope')

@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING the reference's own code.
+
+Runs only in the build container (needs /root/reference, which does not exist
+on the GPU box).  JAX and PySCF are not installable here, so the reference's
+``network.py`` / ``ewaldsum.py`` / ``distance.py`` / ``supercell.py`` /
+``qmc.py`` are imported with in-memory stand-in modules:
+
+  * ``jax.numpy``   -> numpy (``sum`` accepts a list ``axis`` like jnp does)
+  * ``jax.vmap``    -> python loop + stack (tuple outputs, ``None`` in_axes)
+  * ``jax.lax.erfc``-> scipy.special.erfc ; ``jax.jit``/``jax.pmap`` -> identity
+  * ``jax.lax.fori_loop`` -> python loop ; ``jax.random`` -> a recording numpy
+    Generator (so the Metropolis noise can be replayed by the tests)
+  * ``DeepSolid.curvature_tags_and_blocks`` -> identity tags (KFAC bookkeeping)
+  * ``pyscf`` -> empty module; cells are a 20-line attribute bag
+
+No autodiff exists in this stand-in, so ``hamiltonian.py`` cannot be executed;
+kinetic-energy vectors are 4th-order finite differences of the
+reference-executed ``eval_logdet`` (tolerance recorded in the file).
+
+Nothing produced here except the small .npz numbers is shipped.  Parameters
+are NOT stored: they are regenerated from ``oracle.testing.make_test_params``
+(numpy default_rng) and guarded by a checksum.
+"""
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import scipy.special
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = os.environ.get('DEEPSOLID_REFERENCE', '/root/reference')
+
+
+# ----------------------------------------------------------------------------- shim
+class _Recorder:
+    """jax.random stand-in: numpy Generator whose draws are recorded."""
+    def __init__(self):
+        self.reset(0)
+
+    def reset(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.normals, self.uniforms = [], []
+
+    def split(self, key, num=2):
+        return tuple(key for _ in range(num))
+
+    def normal(self, key, shape=()):
+        v = self.rng.standard_normal(shape)
+        self.normals.append(v)
+        return v
+
+    def uniform(self, key, shape=()):
+        v = self.rng.uniform(size=shape)
+        self.uniforms.append(v)
+        return v
+
+    def PRNGKey(self, seed):
+        return np.array([0, seed], dtype=np.uint32)
+
+
+RECORDER = _Recorder()
+
+
+def _install_shim():
+    jnp = types.ModuleType('jax.numpy')
+    for name in dir(np):
+        if not name.startswith('__'):
+            setattr(jnp, name, getattr(np, name))
+
+    def _sum(a, axis=None, **kw):
+        if isinstance(axis, list):
+            axis = tuple(axis)
+        return np.sum(a, axis=axis, **kw)
+    jnp.sum = _sum
+    jnp.DeviceArray = np.ndarray
+    jnp.linalg = np.linalg
+
+    def vmap(f, in_axes=0, out_axes=0):
+        def wrapped(*args):
+            ia = in_axes if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
+            n = next(np.shape(a)[ax] for a, ax in zip(args, ia) if ax is not None)
+            outs = [f(*[a if ax is None else np.take(a, i, axis=ax) for a, ax in zip(args, ia)])
+                    for i in range(n)]
+            if isinstance(outs[0], (tuple, list)):
+                return tuple(np.stack([o[k] for o in outs], axis=out_axes)
+                             for k in range(len(outs[0])))
+            return np.stack(outs, axis=out_axes)
+        return wrapped
+
+    def fori_loop(lo, hi, body, val):
+        for i in range(lo, hi):
+            val = body(i, val)
+        return val
+
+    lax = types.ModuleType('jax.lax')
+    lax.erfc = scipy.special.erfc
+    lax.fori_loop = fori_loop
+    lax.pmean = lambda x, axis_name=None: x
+    lax.psum = lambda x, axis_name=None: x
+
+    core = types.ModuleType('jax.core')
+
+    def axis_frame(name):
+        raise NameError(name)
+    core.axis_frame = axis_frame
+
+    rnd = types.ModuleType('jax.random')
+    for n in ('split', 'normal', 'uniform', 'PRNGKey'):
+        setattr(rnd, n, getattr(RECORDER, n))
+
+    jax = types.ModuleType('jax')
+    jax.numpy, jax.lax, jax.core, jax.random = jnp, lax, core, rnd
+    jax.vmap = vmap
+    jax.jit = lambda f, **kw: f
+    jax.pmap = lambda f, **kw: f
+    sys.modules.update({'jax': jax, 'jax.numpy': jnp, 'jax.lax': lax, 'jax.core': core,
+                        'jax.random': rnd})
+
+    tags = types.ModuleType('DeepSolid.curvature_tags_and_blocks')
+    tags.register_repeated_dense = lambda y, x, w, b: y
+    tags.register_qmc1 = lambda y, x, w, **kw: y
+    sys.modules['DeepSolid.curvature_tags_and_blocks'] = tags
+    for m in ('pyscf', 'pyscf.pbc', 'pyscf.pbc.gto'):
+        sys.modules[m] = types.ModuleType(m)
+    sys.modules['pyscf'].pbc = sys.modules['pyscf.pbc']
+    sys.modules['pyscf.pbc'].gto = sys.modules['pyscf.pbc.gto']
+    sys.modules['pyscf.pbc.gto'].Cell = object
+    sys.path.insert(0, REF)
+
+
+class FakeCell:
+    """The attributes of pyscf.pbc.gto.Cell the reference hot path touches."""
+    def __init__(self, a, coords, charges, nelec):
+        self.a = np.asarray(a, float)
+        self._coords = np.asarray(coords, float).reshape(-1, 3)
+        self._charges = np.asarray(charges)
+        self.nelec = tuple(int(n) for n in nelec)
+        self.nelectron = sum(self.nelec)
+        self.original_cell = self
+        self.S = np.eye(3)
+        self.scale = 1
+
+    def lattice_vectors(self): return self.a
+    def reciprocal_vectors(self): return 2 * np.pi * np.linalg.inv(self.a).T
+    def atom_coords(self): return self._coords
+    def atom_charges(self): return self._charges
+
+
+def ref_supercell(ref_sc, prim, S, nelec):
+    """reference supercell.get_supercell (:64-95) minus the PySCF build()."""
+    S = np.asarray(S, float)
+    Rpts = ref_sc.get_supercell_copies(prim.lattice_vectors(), S)
+    coords, charges = [], []
+    for xyz, q in zip(prim.atom_coords(), prim.atom_charges()):
+        for R in Rpts:
+            coords.append(xyz + R)
+            charges.append(q)
+    sc = FakeCell(np.dot(S, prim.lattice_vectors()), coords, charges, nelec)
+    sc.original_cell = prim
+    sc.S = S
+    sc.scale = abs(int(np.round(np.linalg.det(S))))
+    return ref_sc.set_symmetry_lat(sc, 'minimal')
+
+
+# ----------------------------------------------------------------------------- cases
+def to_np_params(p):
+    def conv(o):
+        if isinstance(o, dict):
+            return {k: conv(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [conv(v) for v in o]
+        return np.asarray(o, dtype=np.float64)
+    return conv(p)
+
+
+def fd_kinetic(f, x, h=2e-3):
+    """-1/2 sum_i [d2f/dx_i^2 + (df/dx_i)^2] by 4th-order central differences of
+    the complex f = log psi (branch of Im f unwrapped against the centre)."""
+    f0 = f(x)
+    tot = 0.0 + 0.0j
+
+    def val(xx):
+        v = f(xx)
+        dphi = np.angle(np.exp(1j * (v.imag - f0.imag)))
+        return v.real + 1j * (f0.imag + dphi)
+    for i in range(x.size):
+        e = np.zeros_like(x); e[i] = h
+        fp1, fm1, fp2, fm2 = val(x + e), val(x - e), val(x + 2 * e), val(x - 2 * e)
+        d1 = (-fp2 + 8 * fp1 - 8 * fm1 + fm2) / (12 * h)
+        d2 = (-fp2 + 16 * fp1 - 30 * f0 + 16 * fm1 - fm2) / (12 * h * h)
+        tot += d2 + d1 * d1
+    return -0.5 * tot
+
+
+def main():
+    _install_shim()
+    from DeepSolid import network as rnet, ewaldsum as rewald, distance as rdist
+    from DeepSolid import supercell as rsc, qmc as rqmc
+    from deepsolid_amd import systems, supercell as my_sc
+    from oracle.testing import make_test_params, params_checksum, klist_from_kpts, CASES
+
+    out_dir = os.path.join(REPO, 'tests', 'golden')
+    os.makedirs(out_dir, exist_ok=True)
+
+    for name, case in CASES.items():
+        my_cell = systems.SYSTEMS[case['system']](**case.get('system_kw', {}))
+        prim0 = my_cell.original_cell
+        # rebuild the cell with the REFERENCE's supercell code from primitive data only
+        prim = FakeCell(prim0.a, prim0.atom_coords(), prim0.atom_charges(), prim0.nelec)
+        sim = ref_supercell(rsc, prim, my_cell.S, my_cell.nelec)
+        kpts = rsc.get_supercell_kpts(sim)
+        twist = np.asarray(case.get('twist', (0, 0, 0)), float)
+        kpts_t = kpts + np.dot(np.linalg.inv(prim.a), np.mod(twist, 1.0)) * 2 * np.pi   # hf.py:61-62
+        klist = klist_from_kpts(kpts_t, sim.nelec)   # grouping shaped like hf.py:99-104
+        N = sum(sim.nelec)
+        net_kw = dict(systems.DETNET_DEFAULTS); net_kw.update(case.get('net_kw', {}))
+        params = make_test_params(case['seed'], prim.atom_coords(), sim.nelec, net_kw)
+        pnp = to_np_params(params)
+        nets = {m: rnet.make_solid_fermi_net(klist=klist, simulation_cell=sim, method_name=m, **net_kw)
+                for m in ('eval_phase_and_slogdet', 'eval_mats', 'eval_logdet', 'eval_slogdet')}
+        B = case.get('batch', 4)
+        x = systems.synthetic_walkers(my_cell, B, seed=case['seed'] + 100)
+        # push some walkers outside the cell so both wraps (primitive, simulation) are exercised
+        rng = np.random.default_rng(case['seed'] + 200)
+        shifts = rng.integers(-2, 3, size=(B, N, 3)) @ sim.a
+        shifts[0] = 0
+        x = x + shifts.reshape(B, -1)
+        d = dict(prim_a=prim.a, prim_atoms=prim.atom_coords(), prim_charges=prim.atom_charges(),
+                 S=sim.S, sim_a=sim.a, sim_atoms=sim.atom_coords(), sim_charges=sim.atom_charges(),
+                 nelec=np.asarray(sim.nelec), prim_AV=prim.AV, prim_BV=prim.BV, sim_AV=sim.AV,
+                 sim_BV=sim.BV, kpts=kpts, twist=twist, klist_up=klist[0], klist_dn=klist[1],
+                 x=x, seed=case['seed'], params_checksum=params_checksum(params))
+        ph, ls, mats = [], [], [[] for _ in range(2)]
+        feats = [[] for _ in range(4)]
+        for b in range(B):
+            p_, l_ = nets['eval_phase_and_slogdet'].apply(pnp, x[b])
+            ph.append(p_); ls.append(l_)
+            m = nets['eval_mats'].apply(pnp, x[b])
+            for s, mm in enumerate(m):
+                mats[s].append(mm)
+            ft = rnet.construct_periodic_input_features(x[b], prim.atom_coords(), simulation_cell=sim,
+                                                        distance_type=net_kw['distance_type'])
+            for k in range(4):
+                feats[k].append(ft[k])
+        d.update(phase=np.asarray(ph), logabs=np.asarray(ls))
+        for s in range(2):
+            if mats[s]:
+                d[f'orbitals_{s}'] = np.asarray(mats[s])
+        for k, nm in enumerate(('feat_ae', 'feat_ee', 'feat_r_ae', 'feat_r_ee')):
+            d[nm] = np.asarray(feats[k])
+
+        # --- Ewald (reference EwaldSum) -------------------------------------------------
+        ew = rewald.EwaldSum(sim)
+        en = np.asarray([[float(v) for v in ew.energy(x[b])] for b in range(B)])
+        d.update(ewald=en, ewald_alpha=float(ew.alpha), ewald_ng=int(ew.gpoints.shape[0]),
+                 ewald_gweight_sum=float(np.sum(ew.gweight)),
+                 ewald_gnorm_sum=float(np.sum(np.linalg.norm(ew.gpoints, axis=1))),
+                 ewald_ion_ion=float(ew.ion_ion), ewald_ii_const=float(ew.ii_const),
+                 dist_mode={'diagonal_dist_i': 0, 'orthogonal_dist_i': 1, 'general_dist_i': 2}[ew.dist.dist_i.__name__])
+        if ew.gpoints.shape[0] < 5000:
+            d.update(ewald_gpoints=np.asarray(ew.gpoints), ewald_gweight=np.asarray(ew.gweight))
+
+        # --- batched wrap (distance.enforce_pbc) ----------------------------------------
+        wx, wrap = rdist.enforce_pbc(sim.a, x)
+        d.update(pbc_x=wx, pbc_wrap=wrap)
+
+        # --- Metropolis: one mh_update and a 3-step mcmc_step with recorded noise --------
+        if case.get('mcmc', True):
+            f_batch = lambda p, xs: np.asarray([nets['eval_slogdet'].apply(p, xx) for xx in xs])
+            lp1 = 2.0 * f_batch(pnp, wx)
+            RECORDER.reset(case['seed'] + 300)
+            xn, _, lpn, nacc = rqmc.mh_update(pnp, f_batch, wx, None, lp1, 0.0, sim.a, stddev=0.05)
+            d.update(mh_x1=wx, mh_lp1=lp1, mh_normal=RECORDER.normals[0], mh_uniform=RECORDER.uniforms[0],
+                     mh_width=0.05, mh_x_new=xn, mh_lp_new=lpn, mh_num_accepts=float(nacc))
+            RECORDER.reset(case['seed'] + 400)
+            step = rqmc.make_mcmc_step(f_batch, B, sim.a, steps=3)
+            xs3, pmove = step(pnp, wx, None, 0.08)
+            d.update(mcmc_x0=wx, mcmc_normals=np.asarray(RECORDER.normals),
+                     mcmc_uniforms=np.asarray(RECORDER.uniforms), mcmc_width=0.08, mcmc_steps=3,
+                     mcmc_x_out=xs3, mcmc_pmove=float(pmove))
+
+        # --- kinetic energy by finite differences of the reference-executed forward -----
+        nfd = case.get('fd_walkers', 0)
+        if nfd:
+            f = lambda xx: complex(nets['eval_logdet'].apply(pnp, xx))
+            h = case.get('fd_h', 2e-3)
+            d.update(ke_fd=np.asarray([fd_kinetic(f, x[b], h=h) for b in range(nfd)]),
+                     ke_fd_h=h, ke_fd_tol=case.get('fd_tol', 5e-6))
+        path = os.path.join(out_dir, name + '.npz')
+        np.savez_compressed(path, **d)
+        print(name, 'N=%d' % N, 'NG=%d' % d['ewald_ng'], 'logabs', d['logabs'][:2],
+              '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    main()
