@@ -1,0 +1,595 @@
+// ds_api.hip -- C-ABI entry points of libdeepsolid_hip.so (see include/deepsolid_hip.h).
+// Host side only: builds the device tables of one simulation cell, carves the caller's
+// workspace and launches the kernels of ds_kernels.h on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/deepsolid_hip.h"
+#include "ds_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_OK(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) return fail("%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+void inv3(const double* a, double* o) {
+    const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) +
+                       a[2] * (a[3] * a[7] - a[4] * a[6]);
+    o[0] = (a[4] * a[8] - a[5] * a[7]) / det; o[1] = (a[2] * a[7] - a[1] * a[8]) / det; o[2] = (a[1] * a[5] - a[2] * a[4]) / det;
+    o[3] = (a[5] * a[6] - a[3] * a[8]) / det; o[4] = (a[0] * a[8] - a[2] * a[6]) / det; o[5] = (a[2] * a[3] - a[0] * a[5]) / det;
+    o[6] = (a[3] * a[7] - a[4] * a[6]) / det; o[7] = (a[1] * a[6] - a[0] * a[7]) / det; o[8] = (a[0] * a[4] - a[1] * a[3]) / det;
+}
+
+// per-walker workspace carve, in elements
+struct WsLayout {
+    size_t G, MEAN, SB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
+    size_t mout_off[2], minv_off[2], dets_off[2], tr_off[2];
+    size_t per_walker;                                     // total elements per walker
+};
+
+}  // namespace
+
+struct ds_system {
+    ds_system_desc d;                 // scalar fields only (pointers invalid after create)
+    int dtype;
+    ds::SysDev<double> sd;
+    ds::SysDev<float> sf;
+    void* blob64 = nullptr;
+    void* blob32 = nullptr;
+    std::vector<ds_param_block> blocks;
+    int64_t nparams = 0;
+    WsLayout ws;
+    // block indices
+    std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_pi, i_sg;
+};
+
+namespace {
+
+template <typename T>
+void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::vector<T>& host) {
+    auto push = [&](const double* p, size_t n) {
+        size_t off = host.size();
+        for (size_t i = 0; i < n; ++i) host.push_back((T)p[i]);
+        while (host.size() % 4) host.push_back(0);
+        return off;
+    };
+    double pinv[9], sinv[9];
+    inv3(d->prim_a, pinv);
+    inv3(d->sim_a, sinv);
+    // lattice displacement tables
+    double disp[81], shift[81];
+    int q = 0;
+    for (int a = -1; a <= 1; ++a)               // ewaldsum.py:54-56 meshgrid 'ij' of arange(-1,2)
+        for (int b = -1; b <= 1; ++b)
+            for (int c = -1; c <= 1; ++c, ++q)
+                for (int k = 0; k < 3; ++k)
+                    disp[3 * q + k] = a * d->sim_a[k] + b * d->sim_a[3 + k] + c * d->sim_a[6 + k];
+    q = 0;
+    for (int a = 0; a < 3; ++a)                 // distance.py:66-68 meshgrid default 'xy': point = (x[b], y[a], z[c]) - 1
+        for (int b = 0; b < 3; ++b)
+            for (int c = 0; c < 3; ++c, ++q)
+                for (int k = 0; k < 3; ++k)
+                    shift[3 * q + k] = (b - 1) * d->sim_a[k] + (a - 1) * d->sim_a[3 + k] + (c - 1) * d->sim_a[6 + k];
+    size_t o_pa = push(d->prim_a, 9), o_pi = push(pinv, 9), o_sa = push(d->sim_a, 9), o_si = push(sinv, 9);
+    size_t o_pav = push(d->prim_AV, 3 * d->n_sym), o_pbv = push(d->prim_BV, 3 * d->n_sym);
+    size_t o_sav = push(d->sim_AV, 3 * d->n_sym), o_sbv = push(d->sim_BV, 3 * d->n_sym);
+    size_t o_at = push(d->prim_atoms, 3 * d->n_atoms_prim);
+    size_t o_k0 = push(d->klist_up, 3 * d->n_up), o_k1 = d->n_dn ? push(d->klist_dn, 3 * d->n_dn) : o_k0;
+    size_t o_sat = push(d->sim_atoms, 3 * d->n_atoms_sim), o_q = push(d->sim_charges, d->n_atoms_sim);
+    size_t o_d27 = push(disp, 81), o_s27 = push(shift, 81);
+    size_t o_g = push(d->gpoints, 3 * (size_t)d->n_g), o_gw = push(d->gweight, d->n_g);
+    size_t o_ir = push(d->ion_exp_re, d->n_g), o_ii = push(d->ion_exp_im, d->n_g);
+    // offsets are turned into pointers after the upload
+    S.prim_a = (const T*)o_pa; S.prim_ainv = (const T*)o_pi; S.sim_a = (const T*)o_sa; S.sim_ainv = (const T*)o_si;
+    S.prim_AV = (const T*)o_pav; S.prim_BV = (const T*)o_pbv; S.sim_AV = (const T*)o_sav; S.sim_BV = (const T*)o_sbv;
+    S.atoms = (const T*)o_at; S.klist[0] = (const T*)o_k0; S.klist[1] = (const T*)o_k1;
+    S.sim_atoms = (const T*)o_sat; S.sim_charges = (const T*)o_q; S.disp27 = (const T*)o_d27; S.shift27 = (const T*)o_s27;
+    S.gpoints = (const T*)o_g; S.gweight = (const T*)o_gw; S.ion_re = (const T*)o_ir; S.ion_im = (const T*)o_ii;
+    S.N = d->n_up + d->n_dn; S.n_up = d->n_up; S.n_dn = d->n_dn; S.A = d->n_atoms_prim; S.L = d->n_sym; S.K = d->n_det;
+    S.nch = d->n_dn > 0 ? 2 : 1;
+    S.D = 3 * S.N + 2; S.P = rup(S.D, 16); S.NP = rup(S.N * S.N, 16);
+    S.n_layers = d->n_layers; S.n_double = d->n_layers - 1;
+    S.h1[0] = 4 * S.A; S.h2[0] = 4;
+    int ldk = 0;
+    for (int l = 0; l < d->n_layers; ++l) {
+        S.h1[l + 1] = d->hidden_single[l];
+        S.h2[l + 1] = d->hidden_double[l];
+        ldk = std::max(ldk, S.h1[l] + S.nch * S.h2[l]);
+    }
+    ldk = std::max(ldk, S.h1[d->n_layers]);
+    S.ldk = ldk;
+    S.nparam[0] = d->n_up * d->n_det; S.nparam[1] = d->n_dn * d->n_det;
+    S.nparam_max = std::max(S.nparam[0], S.nparam[1]);
+    S.ocols[0] = rup(2 * S.nparam[0], 64); S.ocols[1] = rup(2 * S.nparam[1], 64);
+    S.As = d->n_atoms_sim; S.NG = d->n_g; S.dist_mode = d->dist_mode;
+    S.alpha = (T)d->ewald_alpha; S.ee_const = (T)d->ee_const; S.ei_const = (T)d->ei_const; S.ii_total = (T)d->ii_total;
+    (void)s;
+}
+
+template <typename T> void relocate(ds::SysDev<T>& S, const T* base) {
+    auto fix = [&](const T*& p) { p = base + (size_t)p; };
+    fix(S.prim_a); fix(S.prim_ainv); fix(S.sim_a); fix(S.sim_ainv); fix(S.prim_AV); fix(S.prim_BV); fix(S.sim_AV);
+    fix(S.sim_BV); fix(S.atoms); fix(S.klist[0]); fix(S.klist[1]); fix(S.sim_atoms); fix(S.sim_charges); fix(S.disp27);
+    fix(S.shift27); fix(S.gpoints); fix(S.gweight); fix(S.ion_re); fix(S.ion_im);
+}
+
+template <typename T> ds::SysDev<T>& dev(ds_system* s);
+template <> ds::SysDev<double>& dev<double>(ds_system* s) { return s->sd; }
+template <> ds::SysDev<float>& dev<float>(ds_system* s) { return s->sf; }
+
+void build_layouts(ds_system* s) {
+    const ds::SysDev<double>& S = s->sd;
+    int64_t off = 0;
+    auto add = [&](int rows, int cols) {
+        ds_param_block b{off, rows, cols};
+        s->blocks.push_back(b);
+        off += (int64_t)rows * cols;
+        off = (off + 15) / 16 * 16;      // 128-byte alignment of every block
+        return (int)s->blocks.size() - 1;
+    };
+    for (int l = 0; l < S.n_layers; ++l) {
+        s->i_wloc.push_back(add(S.h1[l] + S.nch * S.h2[l], S.h1[l + 1]));
+        s->i_wsh.push_back(add(S.nch * S.h1[l], S.h1[l + 1]));
+        s->i_b.push_back(add(1, S.h1[l + 1]));
+    }
+    for (int l = 0; l < S.n_double; ++l) {
+        s->i_w2.push_back(add(S.h2[l], S.h2[l + 1]));
+        s->i_b2.push_back(add(1, S.h2[l + 1]));
+    }
+    for (int c = 0; c < S.nch; ++c) {
+        s->i_worb.push_back(add(S.h1[S.n_layers], S.ocols[c]));
+        s->i_pi.push_back(add(S.A, S.nparam[c]));
+        s->i_sg.push_back(add(S.A, S.nparam[c]));
+    }
+    s->nparams = off;
+    WsLayout& w = s->ws;
+    int h1max = 0, h2max = 0;
+    for (int l = 0; l <= S.n_layers; ++l) { h1max = std::max(h1max, S.h1[l]); h2max = std::max(h2max, S.h2[l]); }
+    w.G = (size_t)S.N * S.ldk * S.P;
+    w.MEAN = (size_t)S.nch * h1max * S.P;
+    w.SB = (size_t)h1max * S.P;
+    w.H2 = (size_t)h2max * 5 * S.NP;
+    w.Q = (size_t)S.N * S.nparam_max * 10;
+    size_t mo = 0, mi = 0, de = 0, tr = 0;
+    for (int c = 0; c < 2; ++c) {
+        const size_t n = c == 0 ? S.n_up : S.n_dn;
+        w.mout_off[c] = mo; w.minv_off[c] = mi; w.dets_off[c] = de; w.tr_off[c] = tr;
+        mo += (size_t)S.K * n * n * 2 * S.P;
+        mi += (size_t)S.K * n * n * 2;
+        de += (size_t)S.K * 4;
+        tr += (size_t)S.K * 2 * S.P;
+    }
+    w.MOUT = mo; w.MINV = rup((int)mi, 16); w.DETS = rup((int)de, 16); w.TR = tr;
+    w.per_walker = 2 * w.G + 2 * w.MEAN + w.SB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR;
+}
+
+template <typename T> struct Carve {
+    T *G[2], *MEAN[2], *SB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR;
+};
+template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
+    const WsLayout& w = s->ws;
+    T* p = (T*)ws;
+    Carve<T> c;
+    c.G[0] = p; p += w.G * Bc; c.G[1] = p; p += w.G * Bc;
+    c.MEAN[0] = p; p += w.MEAN * Bc; c.MEAN[1] = p; p += w.MEAN * Bc;
+    c.SB = p; p += w.SB * Bc;
+    c.H2[0] = p; p += w.H2 * Bc; c.H2[1] = p; p += w.H2 * Bc;
+    c.Q = p; p += w.Q * Bc;
+    c.MOUT = p; p += w.MOUT * Bc;
+    c.MINV = p; p += w.MINV * Bc;
+    c.DETS = p; p += w.DETS * Bc;
+    c.TR = p; p += w.TR * Bc;
+    return c;
+}
+
+// ---------------------------------------------------------------- launch helpers
+template <typename T, int NB, int ST>
+void launch_single(const ds::SysDev<T>& S, bool res, int64_t Bc, hipStream_t st, const T* Gin, T* Gout, const T* Wloc,
+                   const T* Wsh, const T* b, const T* Min, T* Mout, T* SB, int Kloc, int Ksh, int Nout) {
+    dim3 grid((unsigned)Bc), block(Nout / (16 * NB) * 64);
+    if (res)
+        hipLaunchKernelGGL((ds::k_single_layer<T, NB, ST, true>), grid, block, 0, st, S, Gin, Gout, Wloc, Wsh, b, Min, Mout, SB,
+                           Kloc, Ksh, Nout);
+    else
+        hipLaunchKernelGGL((ds::k_single_layer<T, NB, ST, false>), grid, block, 0, st, S, Gin, Gout, Wloc, Wsh, b, Min, Mout, SB,
+                           Kloc, Ksh, Nout);
+}
+
+template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
+    // (NB, ST): 16*NB output features x 16*ST slots per wave; accumulators = NB*ST tiles
+    switch (st_tiles) {
+        case 1: f(std::integral_constant<int, 4>(), std::integral_constant<int, 1>()); return 0;
+        case 2: f(std::integral_constant<int, 4>(), std::integral_constant<int, 2>()); return 0;
+        case 3: f(std::integral_constant<int, 4>(), std::integral_constant<int, 3>()); return 0;
+        case 4: f(std::integral_constant<int, 4>(), std::integral_constant<int, 4>()); return 0;
+        case 5: f(std::integral_constant<int, 4>(), std::integral_constant<int, 5>()); return 0;
+        case 6: f(std::integral_constant<int, 2>(), std::integral_constant<int, 6>()); return 0;
+        case 7: f(std::integral_constant<int, 2>(), std::integral_constant<int, 7>()); return 0;
+        case 8: f(std::integral_constant<int, 2>(), std::integral_constant<int, 8>()); return 0;
+        case 9: f(std::integral_constant<int, 2>(), std::integral_constant<int, 9>()); return 0;
+        case 10: f(std::integral_constant<int, 2>(), std::integral_constant<int, 10>()); return 0;
+        case 19: f(std::integral_constant<int, 1>(), std::integral_constant<int, 19>()); return 0;
+        default: return 1;
+    }
+}
+
+enum Stop { STOP_NONE = 0, STOP_G0, STOP_G1, STOP_G2, STOP_G3, STOP_H2_0, STOP_H2_1, STOP_H2_2, STOP_MEAN0, STOP_MEAN1, STOP_Q,
+            STOP_MOUT, STOP_MINV, STOP_DETS, STOP_TR };
+
+template <typename T> struct DumpReq { int stop; T* out; int64_t cap; int64_t written; };
+
+template <typename T>
+int copy_out(DumpReq<T>* dr, const T* src, size_t n, hipStream_t st) {
+    size_t m = std::min<size_t>(n, (size_t)dr->cap);
+    HIP_OK(hipMemcpyAsync(dr->out, src, m * sizeof(T), hipMemcpyDeviceToDevice, st));
+    dr->written = (int64_t)m;
+    return 0;
+}
+
+// The forward-Laplacian chain on a chunk of Bc walkers.
+template <typename T>
+int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, hipStream_t st, T* out_ke, T* out_logabs,
+              T* out_phase, DumpReq<T>* dr) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const WsLayout& L = s->ws;
+    Carve<T> c = carve<T>(s, ws, Bc);
+    auto blk = [&](int i) { return params + s->blocks[i].offset; };
+    const int stop = dr ? dr->stop : STOP_NONE;
+    // 1. features
+    {
+        size_t sh = (size_t)(9 * S.N) * sizeof(T) + (size_t)S.N * S.A * 4 * sizeof(ds::Jet5<T>);
+        hipLaunchKernelGGL((ds::k_features<T>), dim3((unsigned)Bc), dim3(256), sh, st, S, x, blk(s->i_pi[0]), blk(s->i_sg[0]),
+                           blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), c.G[0], c.MEAN[0], c.H2[0], c.Q);
+    }
+    if (stop == STOP_MEAN0) return copy_out(dr, c.MEAN[0], (size_t)S.nch * S.h1[0] * S.P * Bc, st);
+    if (stop == STOP_H2_0) return copy_out(dr, c.H2[0], (size_t)S.h2[0] * 5 * S.NP * Bc, st);
+    if (stop == STOP_Q) return copy_out(dr, c.Q, L.Q * Bc, st);
+    int gi = 0, hi = 0, mi = 0;       // current G / H2 / MEAN buffer
+    for (int l = 0; l < S.n_layers; ++l) {
+        const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
+        // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
+        hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc), dim3(256), (size_t)S.nch * K2 * 5 * sizeof(T), st, S,
+                           c.H2[hi], K2, c.G[gi], Kh);
+        if (stop == STOP_G0 + l) return copy_out(dr, c.G[gi], L.G * Bc, st);
+        // pair stream layer
+        if (l < S.n_double) {
+            const int K2o = S.h2[l + 1];
+            if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
+            if (K2 % 4) return fail("pair-stream width %d is not a multiple of 4", K2);
+            dim3 grid((S.NP / 16 + 3) / 4, (unsigned)Bc);
+            const bool res = K2 == K2o;
+            const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
+#define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES>), grid, dim3(256), 0, st, S, c.H2[hi], K2, W2, b2, c.H2[hi ^ 1])
+            if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
+            else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
+#undef DS_TWO
+        }
+        // one-electron stream layer
+        if (Nout % 64 || Nout > 256) return fail("hidden_single must be a multiple of 64 and <= 256 (got %d)", Nout);
+        const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
+        const bool res = Kh == Nout;
+        int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
+            constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
+            launch_single<T, NB, ST>(S, res, Bc, st, c.G[gi], c.G[gi ^ 1], blk(s->i_wloc[l]), blk(s->i_wsh[l]), blk(s->i_b[l]),
+                                     c.MEAN[mi], c.MEAN[mi ^ 1], c.SB, Kloc, Ksh, Nout);
+        });
+        if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
+        gi ^= 1; mi ^= 1;
+        if (l < S.n_double) {
+            hi ^= 1;
+            if (stop == STOP_H2_1 + l) return copy_out(dr, c.H2[hi], (size_t)S.h2[l + 1] * 5 * S.NP * Bc, st);
+        }
+        if (stop == STOP_MEAN1 && l == 0) return copy_out(dr, c.MEAN[mi], (size_t)S.nch * Nout * S.P * Bc, st);
+    }
+    if (stop == STOP_G0 + S.n_layers) return copy_out(dr, c.G[gi], L.G * Bc, st);
+    // orbitals
+    for (int sp = 0; sp < S.nch; ++sp) {
+        int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
+            constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
+            dim3 grid(S.ocols[sp] / (16 * NB), (unsigned)Bc);
+            hipLaunchKernelGGL((ds::k_orbital<T, NB, ST>), grid, dim3(64), 0, st, S, c.G[gi], blk(s->i_worb[sp]), c.Q, c.MOUT, sp,
+                               L.MOUT, L.mout_off[sp]);
+        });
+        if (rc) return fail("no orbital kernel instance for %d slot tiles", S.P / 16);
+    }
+    if (stop == STOP_MOUT) return copy_out(dr, c.MOUT, L.MOUT * Bc, st);
+    // determinants
+    for (int sp = 0; sp < S.nch; ++sp) {
+        const int n = sp == 0 ? S.n_up : S.n_dn;
+        size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
+        hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp,
+                           c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp]);
+    }
+    if (stop == STOP_MINV) return copy_out(dr, c.MINV, L.MINV * Bc, st);
+    for (int sp = 0; sp < S.nch; ++sp) {
+        const int n = sp == 0 ? S.n_up : S.n_dn;
+#define DS_TRACE(NMAX, SP)                                                                                                    \
+    do {                                                                                                                      \
+        size_t sh = ((size_t)n * n + (size_t)SP * n * n + 256) * sizeof(ds::Cx<T>);                                             \
+        hipLaunchKernelGGL((ds::k_det_trace<T, NMAX, SP>), dim3(S.K, (unsigned)Bc), dim3(256), sh, st, S, c.MOUT, L.MOUT,      \
+                           L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,        \
+                           L.dets_off[sp]);                                                                                    \
+    } while (0)
+        if (n <= 16) DS_TRACE(16, 16);
+        else if (n <= 32) DS_TRACE(32, 8);
+        else if (n <= 64) DS_TRACE(64, 4);
+        else return fail("n_s = %d > 64 electrons per spin is not supported", n);
+#undef DS_TRACE
+    }
+    if (stop == STOP_DETS) return copy_out(dr, c.DETS, L.DETS * Bc, st);
+    if (stop == STOP_TR) return copy_out(dr, c.TR, L.TR * Bc, st);
+    hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, c.TR, L.TR, L.tr_off[1], c.DETS, L.DETS,
+                       L.dets_off[1], out_ke, out_logabs, out_phase);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B, void* out_ke, void* out_ewald, void* out_logabs,
+                      void* out_phase, void* ws, int64_t ws_bytes, hipStream_t st) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T));
+    if (chunk < 1) return fail("workspace too small: %lld bytes < %zu per walker", (long long)ws_bytes, s->ws.per_walker * sizeof(T));
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t Bc = std::min(chunk, B - b0);
+        const T* xb = (const T*)x + b0 * 3 * S.N;
+        int rc = run_chain<T>(s, (const T*)params, xb, Bc, ws, st, out_ke ? (T*)out_ke + 2 * b0 : nullptr,
+                              out_logabs ? (T*)out_logabs + b0 : nullptr, out_phase ? (T*)out_phase + 2 * b0 : nullptr, nullptr);
+        if (rc) return rc;
+    }
+    if (out_ewald) {
+        // ee + ei + ii summed into one number per walker by a tiny epilogue: reuse the workspace head
+        T* tmp = (T*)ws;
+        for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+            const int64_t Bc = std::min(chunk, B - b0);
+            size_t sh = (size_t)(3 * S.N + 512) * sizeof(T);
+            hipLaunchKernelGGL((ds::k_ewald<T>), dim3((unsigned)Bc), dim3(256), sh, st, S, (const T*)x + b0 * 3 * S.N, tmp);
+            hipLaunchKernelGGL((ds::k_sum3<T>), dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, tmp, Bc, (T*)out_ewald + b0);
+        }
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int check_arch(const ds_system_desc* d) {
+    if (d->dtype != 0 && d->dtype != 1) return fail("dtype must be 0 (f64) or 1 (f32)");
+    if (d->distance_type != 0) return fail("only distance_type='nu' is implemented on the device");
+    if (d->envelope_type != 0) return fail("only envelope_type='isotropic' is implemented on the device");
+    if (d->full_det) return fail("full_det=True is not implemented on the device");
+    if (d->use_last_layer) return fail("use_last_layer=True is not implemented on the device");
+    if (d->bias_orbitals) return fail("bias_orbitals=True is not implemented on the device");
+    if (d->n_up < 1) return fail("n_up must be >= 1");
+    if (d->n_dn > d->n_up) return fail("n_dn > n_up is not supported");
+    if (d->n_layers < 1 || d->n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
+    if (d->n_det < 1 || d->n_det > 32) return fail("n_det must be in 1..32");
+    if ((d->n_up * d->n_det) % 8 || (d->n_dn * d->n_det) % 8) return fail("n_s * n_det must be a multiple of 8");
+    if (d->n_sym < 3 || d->n_sym > DS_MAX_SYM) return fail("bad n_sym");
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* ds_last_error(void) { return g_err.c_str(); }
+
+int ds_system_create(const ds_system_desc* desc, ds_system** out) {
+    if (!desc || !out) return fail("null argument");
+    if (int rc = check_arch(desc)) return rc;
+    ds_system* s = new ds_system();
+    s->d = *desc;
+    s->dtype = desc->dtype;
+    std::vector<double> h64;
+    std::vector<float> h32;
+    fill_tables<double>(s, desc, s->sd, h64);
+    fill_tables<float>(s, desc, s->sf, h32);
+    if (hipMalloc(&s->blob64, h64.size() * sizeof(double)) != hipSuccess || hipMalloc(&s->blob32, h32.size() * sizeof(float)) != hipSuccess) {
+        delete s;
+        return fail("hipMalloc of the system tables failed (is a GPU visible?)");
+    }
+    hipMemcpy(s->blob64, h64.data(), h64.size() * sizeof(double), hipMemcpyHostToDevice);
+    hipMemcpy(s->blob32, h32.data(), h32.size() * sizeof(float), hipMemcpyHostToDevice);
+    relocate<double>(s->sd, (const double*)s->blob64);
+    relocate<float>(s->sf, (const float*)s->blob32);
+    build_layouts(s);
+    *out = s;
+    return 0;
+}
+
+void ds_system_destroy(ds_system* s) {
+    if (!s) return;
+    if (s->blob64) hipFree(s->blob64);
+    if (s->blob32) hipFree(s->blob32);
+    delete s;
+}
+
+int64_t ds_param_count(const ds_system* s) { return s ? s->nparams : -1; }
+
+int ds_param_layout(const ds_system* s, ds_param_block* blocks, int max_blocks) {
+    if (!s) return -1;
+    const int n = (int)s->blocks.size();
+    for (int i = 0; i < n && i < max_blocks; ++i) blocks[i] = s->blocks[i];
+    return n;
+}
+
+int64_t ds_workspace_bytes(const ds_system* s, int64_t B) {
+    if (!s) return -1;
+    const int64_t esz = s->dtype == 0 ? 8 : 4;
+    const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 1024);
+    return (int64_t)s->ws.per_walker * esz * chunk + 256;
+}
+
+int ds_local_energy(ds_system* s, const void* params, const void* x, int64_t B, void* out_ke, void* out_ewald, void* out_logabs,
+                    void* out_phase, void* ws, int64_t ws_bytes, void* stream) {
+    if (!s || !params || !x || !ws) return fail("null argument");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return s->dtype == 0 ? local_energy_impl<double>(s, params, x, B, out_ke, out_ewald, out_logabs, out_phase, ws, ws_bytes, st)
+                         : local_energy_impl<float>(s, params, x, B, out_ke, out_ewald, out_logabs, out_phase, ws, ws_bytes, st);
+}
+
+int ds_logpsi(ds_system* s, const void* params, const void* x, int64_t B, void* out_logabs, void* out_phase, void* ws,
+              int64_t ws_bytes, void* stream) {
+    // round 1: the value rides in slot 0 of the forward-Laplacian chain
+    return ds_local_energy(s, params, x, B, nullptr, nullptr, out_logabs, out_phase, ws, ws_bytes, stream);
+}
+
+int ds_ewald(ds_system* s, const void* x, int64_t B, void* out, void* stream) {
+    if (!s || !x || !out) return fail("null argument");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->dtype == 0) {
+        size_t sh = (size_t)(3 * s->sd.N + 512) * sizeof(double);
+        hipLaunchKernelGGL((ds::k_ewald<double>), dim3((unsigned)B), dim3(256), sh, st, s->sd, (const double*)x, (double*)out);
+    } else {
+        size_t sh = (size_t)(3 * s->sf.N + 512) * sizeof(float);
+        hipLaunchKernelGGL((ds::k_ewald<float>), dim3((unsigned)B), dim3(256), sh, st, s->sf, (const float*)x, (float*)out);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int ds_enforce_pbc(const double* latvec, int dtype, const void* x, int64_t n_elec, void* out_x, void* out_wrap, void* stream) {
+    if (!latvec || !x || !out_x) return fail("null argument");
+    if (n_elec <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    double inv[9];
+    inv3(latvec, inv);
+    dim3 grid((unsigned)((n_elec + 255) / 256)), block(256);
+    if (dtype == 0) {
+        ds::Lattice<double> L;
+        for (int i = 0; i < 9; ++i) { L.a[i] = latvec[i]; L.ainv[i] = inv[i]; }
+        hipLaunchKernelGGL((ds::k_enforce_pbc<double>), grid, block, 0, st, L, (const double*)x, (size_t)n_elec, (double*)out_x,
+                           (double*)out_wrap);
+    } else if (dtype == 1) {
+        ds::Lattice<float> L;
+        for (int i = 0; i < 9; ++i) { L.a[i] = (float)latvec[i]; L.ainv[i] = (float)inv[i]; }
+        hipLaunchKernelGGL((ds::k_enforce_pbc<float>), grid, block, 0, st, L, (const float*)x, (size_t)n_elec, (float*)out_x,
+                           (float*)out_wrap);
+    } else {
+        return fail("dtype must be 0 or 1");
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int ds_mh_propose(ds_system* s, const void* x1, const void* normal, double width, int64_t B, void* x2, void* stream) {
+    if (!s || !x1 || !normal || !x2) return fail("null argument");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ne = (size_t)B * s->sd.N;
+    dim3 grid((unsigned)((ne + 255) / 256)), block(256);
+    if (s->dtype == 0)
+        hipLaunchKernelGGL((ds::k_mh_propose<double>), grid, block, 0, st, s->sd.sim_a, s->sd.sim_ainv, (const double*)x1,
+                           (const double*)normal, width, ne, (double*)x2);
+    else
+        hipLaunchKernelGGL((ds::k_mh_propose<float>), grid, block, 0, st, s->sf.sim_a, s->sf.sim_ainv, (const float*)x1,
+                           (const float*)normal, (float)width, ne, (float*)x2);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int ds_mh_accept(ds_system* s, void* x1, void* lp1, const void* x2, const void* lp2, const void* uniform, int64_t B, void* n_accept,
+                 void* stream) {
+    if (!s || !x1 || !lp1 || !x2 || !lp2 || !uniform || !n_accept) return fail("null argument");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (s->dtype == 0)
+        hipLaunchKernelGGL((ds::k_mh_accept<double>), dim3((unsigned)B), dim3(64), 0, st, (double*)x1, (double*)lp1, (const double*)x2,
+                           (const double*)lp2, (const double*)uniform, 3 * s->sd.N, (double*)n_accept);
+    else
+        hipLaunchKernelGGL((ds::k_mh_accept<float>), dim3((unsigned)B), dim3(64), 0, st, (float*)x1, (float*)lp1, (const float*)x2,
+                           (const float*)lp2, (const float*)uniform, 3 * s->sf.N, (float*)n_accept);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int ds_orbitals(ds_system* s, const void* params, const void* x, int64_t B, void* out_up, void* out_dn, void* ws, int64_t ws_bytes,
+                void* stream) {
+    if (!s || !params || !x || !ws || !out_up) return fail("null argument");
+    if (s->dtype != 0) return fail("ds_orbitals: f64 only in this build");
+    hipStream_t st = (hipStream_t)stream;
+    const ds::SysDev<double>& S = s->sd;
+    const int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(double));
+    if (chunk < 1) return fail("workspace too small");
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t Bc = std::min(chunk, B - b0);
+        DumpReq<double> dr{STOP_MOUT, nullptr, 0, 0};
+        // run up to MOUT without copying (cap 0), then gather slot 0
+        dr.out = (double*)ws; dr.cap = 0;
+        int rc = run_chain<double>(s, (const double*)params, (const double*)x + b0 * 3 * S.N, Bc, ws, st, nullptr, nullptr, nullptr, &dr);
+        if (rc) return rc;
+        Carve<double> c = carve<double>(s, ws, Bc);
+        for (int sp = 0; sp < S.nch; ++sp) {
+            const int n = sp == 0 ? S.n_up : S.n_dn;
+            double* o = (double*)(sp == 0 ? out_up : out_dn);
+            if (!o) continue;
+            const size_t per = (size_t)S.K * n * n * 2;
+            hipLaunchKernelGGL((ds::k_gather_slot0<double>), dim3((unsigned)((per + 255) / 256), (unsigned)Bc), dim3(256), 0, st,
+                               c.MOUT, s->ws.MOUT, s->ws.mout_off[sp], per, S.P, o + b0 * per);
+        }
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int64_t ds_debug_stage(ds_system* s, const void* params, const void* x, int64_t B, const char* stage, void* out, int64_t out_elems,
+                       void* ws, int64_t ws_bytes, void* stream) {
+    if (!s || !params || !x || !stage || !out || !ws) { fail("null argument"); return -1; }
+    static const struct { const char* name; int stop; } names[] = {
+        {"g0", STOP_G0}, {"g1", STOP_G1}, {"g2", STOP_G2}, {"g3", STOP_G3}, {"h2_0", STOP_H2_0}, {"h2_1", STOP_H2_1},
+        {"h2_2", STOP_H2_2}, {"mean0", STOP_MEAN0}, {"mean1", STOP_MEAN1}, {"q", STOP_Q}, {"mout", STOP_MOUT},
+        {"minv", STOP_MINV}, {"dets", STOP_DETS}, {"tr", STOP_TR}};
+    int stop = -1;
+    for (auto& n : names)
+        if (!strcmp(n.name, stage)) stop = n.stop;
+    if (stop < 0) { fail("unknown stage '%s'", stage); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t esz = s->dtype == 0 ? 8 : 4;
+    const int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * esz);
+    if (chunk < B) { fail("debug stage needs the whole batch in one chunk"); return -1; }
+    int rc;
+    int64_t written;
+    if (s->dtype == 0) {
+        DumpReq<double> dr{stop, (double*)out, out_elems, 0};
+        rc = run_chain<double>(s, (const double*)params, (const double*)x, B, ws, st, nullptr, nullptr, nullptr, &dr);
+        written = dr.written;
+    } else {
+        DumpReq<float> dr{stop, (float*)out, out_elems, 0};
+        rc = run_chain<float>(s, (const float*)params, (const float*)x, B, ws, st, nullptr, nullptr, nullptr, &dr);
+        written = dr.written;
+    }
+    return rc ? -1 : written;
+}
+
+int64_t ds_mfma_f64_peak(int64_t iters, void* scratch, void* stream) {
+    const int blocks = 256 * 2;   // two 4-wave blocks per CU
+    hipLaunchKernelGGL(ds::k_mfma_peak, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)iters, (double*)scratch);
+    return (int64_t)blocks * 4 * iters * 8 * 2048;   // waves * iters * mfma per iter * flop per mfma
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+// ds_device.h -- device-side building blocks for the gfx950 kernels.
+//
+//  * mfma_tile: one v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 step and the
+//    lane <-> (row, col) maps of its accumulator (the f64 map differs from f32).
+//  * Jet5: (value, 3-gradient, 3-Laplacian) forward-mode number used for the
+//    periodic input features of reference network.py:189-224 / 249-302.
+//  * small complex helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define DS_PI 3.14159265358979323846
+
+namespace ds {
+
+template <typename T> struct Acc4;
+template <> struct Acc4<double> { typedef double type __attribute__((ext_vector_type(4))); };
+template <> struct Acc4<float> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// D(16x16) += A(16x4) * B(4x16).  Operand placement for BOTH dtypes:
+//   a = A[row = lane & 15][k = lane >> 4],  b = B[k = lane >> 4][col = lane & 15]
+// Accumulator placement (col = lane & 15 for both):
+//   f64: row = (lane >> 4) + 4 * reg          f32: row = 4 * (lane >> 4) + reg
+__device__ __forceinline__ Acc4<double>::type mfma16(double a, double b, Acc4<double>::type c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ Acc4<float>::type mfma16(float a, float b, Acc4<float>::type c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ int acc_row(int lane, int reg);
+template <> __device__ __forceinline__ int acc_row<double>(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+template <> __device__ __forceinline__ int acc_row<float>(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+
+// ------------------------------------------------------------------ math wrappers
+__device__ __forceinline__ double ds_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ float ds_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double ds_exp(double x) { return exp(x); }
+__device__ __forceinline__ float ds_exp(float x) { return expf(x); }
+__device__ __forceinline__ double ds_log(double x) { return log(x); }
+__device__ __forceinline__ float ds_log(float x) { return logf(x); }
+__device__ __forceinline__ double ds_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float ds_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double ds_floor(double x) { return floor(x); }
+__device__ __forceinline__ float ds_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double ds_erfc(double x) { return erfc(x); }
+__device__ __forceinline__ float ds_erfc(float x) { return erfcf(x); }
+__device__ __forceinline__ double ds_fmod(double x, double y) { return fmod(x, y); }
+__device__ __forceinline__ float ds_fmod(float x, float y) { return fmodf(x, y); }
+__device__ __forceinline__ double ds_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float ds_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ void ds_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+__device__ __forceinline__ void ds_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+template <typename T> __device__ __forceinline__ T ds_abs(T x) { return x < T(0) ? -x : x; }
+template <typename T> __device__ __forceinline__ T ds_sign(T x) { return x > T(0) ? T(1) : (x < T(0) ? T(-1) : T(0)); }
+// jnp.remainder / python % : result has the sign of the divisor
+template <typename T> __device__ __forceinline__ T ds_pymod(T x, T y) {
+    T r = ds_fmod(x, y);
+    if (r != T(0) && ((r < T(0)) != (y < T(0)))) r += y;
+    return r;
+}
+
+// ------------------------------------------------------------------ complex
+template <typename T> struct Cx {
+    T re, im;
+    __device__ __forceinline__ Cx() {}
+    __device__ __forceinline__ Cx(T r, T i) : re(r), im(i) {}
+};
+template <typename T> __device__ __forceinline__ Cx<T> operator+(Cx<T> a, Cx<T> b) { return Cx<T>(a.re + b.re, a.im + b.im); }
+template <typename T> __device__ __forceinline__ Cx<T> operator-(Cx<T> a, Cx<T> b) { return Cx<T>(a.re - b.re, a.im - b.im); }
+template <typename T> __device__ __forceinline__ Cx<T> operator*(Cx<T> a, Cx<T> b) {
+    return Cx<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+template <typename T> __device__ __forceinline__ Cx<T> operator*(T s, Cx<T> a) { return Cx<T>(s * a.re, s * a.im); }
+template <typename T> __device__ __forceinline__ Cx<T> cx_fma(Cx<T> a, Cx<T> b, Cx<T> c) {   // a*b + c
+    return Cx<T>(fma(a.re, b.re, fma(-a.im, b.im, c.re)), fma(a.re, b.im, fma(a.im, b.re, c.im)));
+}
+template <typename T> __device__ __forceinline__ T cx_abs2(Cx<T> a) { return a.re * a.re + a.im * a.im; }
+template <typename T> __device__ __forceinline__ Cx<T> cx_inv(Cx<T> a) {
+    T d = T(1) / cx_abs2(a);
+    return Cx<T>(a.re * d, -a.im * d);
+}
+
+// ------------------------------------------------------------------ Jet5
+// value / gradient (3) / Laplacian of a scalar function of ONE relative vector r in R^3.
+template <typename T> struct Jet5 {
+    T v, g[3], l;
+};
+template <typename T> __device__ __forceinline__ Jet5<T> jet_zero() {
+    Jet5<T> j; j.v = 0; j.g[0] = j.g[1] = j.g[2] = 0; j.l = 0; return j;
+}
+template <typename T> __device__ __forceinline__ Jet5<T> jet_add(Jet5<T> a, Jet5<T> b) {
+    Jet5<T> o; o.v = a.v + b.v; o.l = a.l + b.l;
+    for (int c = 0; c < 3; ++c) o.g[c] = a.g[c] + b.g[c];
+    return o;
+}
+template <typename T> __device__ __forceinline__ Jet5<T> jet_scale(T s, Jet5<T> a) {
+    Jet5<T> o; o.v = s * a.v; o.l = s * a.l;
+    for (int c = 0; c < 3; ++c) o.g[c] = s * a.g[c];
+    return o;
+}
+template <typename T> __device__ __forceinline__ Jet5<T> jet_mul(Jet5<T> a, Jet5<T> b) {
+    Jet5<T> o;
+    o.v = a.v * b.v;
+    T dot = 0;
+    for (int c = 0; c < 3; ++c) { o.g[c] = a.g[c] * b.v + a.v * b.g[c]; dot += a.g[c] * b.g[c]; }
+    o.l = a.l * b.v + a.v * b.l + 2 * dot;
+    return o;
+}
+// phi(a) given phi, phi', phi'' at a.v
+template <typename T> __device__ __forceinline__ Jet5<T> jet_fn(Jet5<T> a, T p0, T p1, T p2) {
+    Jet5<T> o;
+    o.v = p0;
+    T n2 = 0;
+    for (int c = 0; c < 3; ++c) { o.g[c] = p1 * a.g[c]; n2 += a.g[c] * a.g[c]; }
+    o.l = p1 * a.l + p2 * n2;
+    return o;
+}
+
+// Periodic generalized distance of reference network.py:207-224 ('nu'), as jets in r.
+//   av, bv: (L,3) rows of AV / BV;  out[0] = sd, out[1..3] = rel
+// Autodiff conventions follow JAX: d|w|/dw = sign(w), floor has zero derivative.
+template <typename T>
+__device__ __forceinline__ void nu_distance_jet(const T r[3], const T* __restrict__ av, const T* __restrict__ bv,
+                                                int L, Jet5<T> out[4]) {
+    const T pi = T(DS_PI);
+    Jet5<T> F[6], G[6];
+    for (int l = 0; l < L; ++l) {
+        const T b0 = bv[3 * l], b1 = bv[3 * l + 1], b2 = bv[3 * l + 2];
+        T w = r[0] * b0 + r[1] * b1 + r[2] * b2;
+        const T mod = ds_floor((w + pi) / (2 * pi));
+        w = w - mod * 2 * pi;
+        const T aw = ds_abs(w / pi), sg = ds_sign(w);
+        Jet5<T> wj; wj.v = w; wj.g[0] = b0; wj.g[1] = b1; wj.g[2] = b2; wj.l = 0;
+        // f = |w| (1 - |w/pi|^3 / 4): f' = sign(w)(1 - |w/pi|^3), f'' = -3 (w/pi)^2 / pi
+        const T f0 = ds_abs(w) * (1 - aw * aw * aw / 4);
+        const T f1 = sg * (1 - aw * aw * aw);
+        const T f2 = -3 * aw * aw / pi;
+        // g = w (1 - 1.5|w/pi| + 0.5 (w/pi)^2): g' = 1 - 3|w/pi| + 1.5 (w/pi)^2, g'' = (-3 sign(w) + 3 w/pi)/pi
+        const T g0 = w * (1 - T(1.5) * aw + T(0.5) * aw * aw);
+        const T g1 = 1 - 3 * aw + T(1.5) * aw * aw;
+        const T g2 = (-3 * sg + 3 * w / pi) / pi;
+        F[l] = jet_fn(wj, f0, f1, f2);
+        G[l] = jet_fn(wj, g0, g1, g2);
+    }
+    Jet5<T> s2 = jet_zero<T>();
+    for (int l = 0; l < L; ++l) {
+        const T n2 = av[3 * l] * av[3 * l] + av[3 * l + 1] * av[3 * l + 1] + av[3 * l + 2] * av[3 * l + 2];
+        s2 = jet_add(s2, jet_scale(n2, jet_mul(F[l], F[l])));
+        for (int m = 0; m < L; ++m) {
+            if (m == l) continue;
+            const T dot = av[3 * l] * av[3 * m] + av[3 * l + 1] * av[3 * m + 1] + av[3 * l + 2] * av[3 * m + 2];
+            s2 = jet_add(s2, jet_scale(dot, jet_mul(G[l], G[m])));
+        }
+    }
+    const T sd = ds_sqrt(s2.v);
+    out[0] = jet_fn(s2, sd, T(0.5) / sd, T(-0.25) / (sd * s2.v));
+    for (int c = 0; c < 3; ++c) {
+        Jet5<T> rc = jet_zero<T>();
+        for (int l = 0; l < L; ++l) rc = jet_add(rc, jet_scale(av[3 * l + c], G[l]));
+        out[1 + c] = rc;
+    }
+}
+
+// x (Cartesian) -> wrapped into the cell: frac = x @ inv; frac - floor(frac); @ a   (network.py:42-57)
+template <typename T>
+__device__ __forceinline__ void wrap_point(const T x[3], const T* __restrict__ a, const T* __restrict__ ainv, T out[3],
+                                           T wrap[3]) {
+    T fr[3];
+    for (int c = 0; c < 3; ++c) {
+        T f = x[0] * ainv[c] + x[1] * ainv[3 + c] + x[2] * ainv[6 + c];
+        wrap[c] = ds_floor(f);
+        fr[c] = f - wrap[c];
+    }
+    for (int c = 0; c < 3; ++c) out[c] = fr[0] * a[c] + fr[1] * a[3 + c] + fr[2] * a[6 + c];
+}
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+}  // namespace ds

@@ -1,0 +1,313 @@
+"""DeviceSystem: one simulation cell + network architecture resident on one GPU.
+
+Owns the C-ABI handle (``ds_system``), the packed parameter buffer and the
+scratch workspace; every numeric call of the package ends in one of the
+``ds_*`` entry points of libdeepsolid_hip.so here.  Walkers, parameters and
+results are torch tensors on the ROCm device -- torch is used for memory,
+streams and (elsewhere) torch.distributed, nothing else.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import distance as _distance
+
+_DTYPES = {torch.float64: 0, torch.float32: 1}
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError('deepsolid_amd needs a ROCm GPU: there is no CPU path (the CPU oracle lives in '
+                           'oracle/ and is test infrastructure only)')
+
+
+class DeviceSystem:
+    def __init__(self, simulation_cell, klist, net_kw, tables, dtype=torch.float64, device=None):
+        _require_gpu()
+        self.lib = _lib.load()
+        self.cell = simulation_cell
+        self.dtype = dtype
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.net_kw = dict(net_kw)
+        self.tables = tables
+        prim = simulation_cell.original_cell
+        self.nelec = tuple(int(n) for n in simulation_cell.nelec)
+        self.n = sum(self.nelec)
+        self.n_det = int(net_kw['determinants'])
+        self.hidden_dims = tuple(tuple(int(v) for v in h) for h in net_kw['hidden_dims'])
+        d = _lib.SystemDesc()
+        keep = []                       # host arrays must outlive ds_system_create
+
+        def arr(a):
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+            keep.append(a)
+            return _pd(a)
+        d.dtype = _DTYPES[dtype]
+        d.n_up, d.n_dn = self.nelec
+        atoms = np.asarray(prim.atom_coords(), dtype=np.float64).reshape(-1, 3)
+        d.n_atoms_prim = atoms.shape[0]
+        d.prim_atoms = arr(atoms)
+        d.prim_a[:] = np.asarray(prim.a, dtype=np.float64).reshape(-1).tolist()
+        d.sim_a[:] = np.asarray(simulation_cell.a, dtype=np.float64).reshape(-1).tolist()
+        n_sym = np.asarray(simulation_cell.AV).shape[0]
+        d.n_sym = n_sym
+        for name, src in (('prim_AV', prim.AV), ('prim_BV', prim.BV), ('sim_AV', simulation_cell.AV),
+                          ('sim_BV', simulation_cell.BV)):
+            flat = np.zeros(_lib.DS_MAX_SYM * 3)
+            flat[:3 * n_sym] = np.asarray(src, dtype=np.float64).reshape(-1)
+            getattr(d, name)[:] = flat.tolist()
+        d.n_layers = len(self.hidden_dims)
+        for i, (a, b) in enumerate(self.hidden_dims):
+            d.hidden_single[i], d.hidden_double[i] = a, b
+        d.n_det = self.n_det
+        d.distance_type = {'nu': 0, 'tri': 1}.get(net_kw.get('distance_type', 'nu'), 99)
+        d.envelope_type = {'isotropic': 0, 'diagonal': 1, 'full': 2}.get(net_kw.get('envelope_type'), 99)
+        d.full_det = int(bool(net_kw.get('full_det', False)))
+        d.use_last_layer = int(bool(net_kw.get('use_last_layer', False)))
+        d.bias_orbitals = int(bool(net_kw.get('bias_orbitals', False)))
+        kl = [np.asarray(k, dtype=np.float64).reshape(-1, 3) for k in klist]
+        if kl[0].shape[0] != self.nelec[0] or kl[1].shape[0] != self.nelec[1]:
+            raise ValueError('klist must hold one k vector per electron of each spin (hf.py:99-104)')
+        d.klist_up, d.klist_dn = arr(kl[0]), arr(kl[1] if kl[1].size else np.zeros((1, 3)))
+        t = tables
+        d.n_atoms_sim = t.atom_coords.shape[0]
+        d.sim_atoms, d.sim_charges = arr(t.atom_coords), arr(t.atom_charges)
+        d.dist_mode = t.dist_mode
+        d.n_g = t.gpoints.shape[0]
+        d.gpoints, d.gweight = arr(t.gpoints), arr(t.gweight)
+        d.ion_exp_re, d.ion_exp_im = arr(t.ion_exp.real), arr(t.ion_exp.imag)
+        d.ewald_alpha = float(t.alpha)
+        d.ee_const, d.ei_const = float(t.ee_const(self.n)), float(t.ei_const(self.n))
+        d.ii_total = float(t.ion_ion + t.ii_const)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ds_system_create(C.byref(d), C.byref(handle)), 'ds_system_create')
+        self.handle = handle
+        nb = self.lib.ds_param_layout(handle, None, 0)
+        blocks = (_lib.ParamBlock * nb)()
+        self.lib.ds_param_layout(handle, blocks, nb)
+        self.blocks = [(int(b.offset), int(b.rows), int(b.cols)) for b in blocks]
+        self.param_count = int(self.lib.ds_param_count(handle))
+        self._ws = None
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def for_network(cls, simulation_cell, klist, net_kw, dtype=torch.float64):
+        from .ewaldsum import EwaldTables
+        key = ('net', id(simulation_cell), dtype, repr(sorted(net_kw.items())),
+               tuple(np.asarray(k).tobytes() for k in klist))
+        cache = simulation_cell.__dict__.setdefault('_ds_cache', {})
+        if key not in cache:
+            tables = cache.get('tables')
+            if tables is None:
+                tables = cache['tables'] = EwaldTables(simulation_cell)
+            cache[key] = cls(simulation_cell, klist, net_kw, tables, dtype)
+        return cache[key]
+
+    @classmethod
+    def for_ewald(cls, simulation_cell, tables=None, dtype=torch.float64):
+        """Ewald-only handle: a dummy minimal network description."""
+        from .ewaldsum import EwaldTables
+        from .supercell import make_klist
+        cache = simulation_cell.__dict__.setdefault('_ds_cache', {})
+        key = ('ewald', dtype)
+        if key not in cache:
+            tables = tables or cache.get('tables') or EwaldTables(simulation_cell)
+            cache['tables'] = tables
+            nk = dict(envelope_type='isotropic', bias_orbitals=False, use_last_layer=False, full_det=False,
+                      hidden_dims=((64, 16), (64, 16)), determinants=8, distance_type='nu')
+            if getattr(simulation_cell, 'AV', None) is None:
+                from .supercell import set_symmetry_lat
+                set_symmetry_lat(simulation_cell)
+            klist = make_klist(simulation_cell)
+            cache[key] = cls(simulation_cell, klist, nk, tables, dtype)
+        return cache[key]
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.ds_system_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ buffers
+    def _check_x(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('walkers must be a tensor on the ROCm device (no CPU path)')
+        if x.dtype != self.dtype:
+            raise TypeError(f'walkers are {x.dtype}, system was built for {self.dtype}')
+        if x.dim() != 2 or x.shape[1] != 3 * self.n:
+            raise ValueError(f'walkers must be (B, {3 * self.n}), got {tuple(x.shape)}')
+        return x.contiguous()
+
+    def workspace(self, B, max_bytes=None):
+        need = int(self.lib.ds_workspace_bytes(self.handle, int(B)))
+        if max_bytes is not None:
+            need = min(need, int(max_bytes))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def pack_params(self, params):
+        """Reference parameter tree (network.py:135-186) -> the flat device buffer of
+        include/deepsolid_hip.h (`ds_param_layout`).  Cached on the leaves' versions."""
+        leaves = []
+
+        def walk(o):
+            if isinstance(o, dict):
+                for k in sorted(o):
+                    walk(o[k])
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v)
+            else:
+                leaves.append(o)
+        walk(params)
+        key = tuple((id(t), getattr(t, '_version', 0)) for t in leaves)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+
+        def dev(a):
+            if not isinstance(a, torch.Tensor):
+                a = torch.as_tensor(np.asarray(a))
+            return a.to(device=self.device, dtype=self.dtype)
+        flat = torch.zeros(self.param_count, dtype=self.dtype, device=self.device)
+        nch = 2 if self.nelec[1] > 0 else 1
+        bi = iter(self.blocks)
+
+        def put(mat):
+            off, rows, cols = next(bi)
+            mat = mat.reshape(rows, cols) if mat.numel() == rows * cols else mat
+            if tuple(mat.shape) != (rows, cols):
+                raise ValueError(f'parameter block shape {tuple(mat.shape)} != expected {(rows, cols)}')
+            flat[off:off + rows * cols] = mat.reshape(-1)
+        natom = np.asarray(self.cell.original_cell.atom_coords()).reshape(-1, 3).shape[0]
+        h1 = [4 * natom] + [h[0] for h in self.hidden_dims]
+        h2 = [4] + [h[1] for h in self.hidden_dims]
+        for l in range(len(self.hidden_dims)):
+            w = dev(params['single'][l]['w'])
+            kh, k2 = h1[l], h2[l]
+            if w.shape[0] != (nch + 1) * kh + nch * k2:
+                raise ValueError(f"single[{l}]['w'] has {w.shape[0]} rows, expected {(nch + 1) * kh + nch * k2}")
+            put(torch.cat([w[:kh], w[(nch + 1) * kh:]], dim=0))          # per-electron rows
+            put(w[kh:(nch + 1) * kh])                                    # spin-mean rows
+            put(dev(params['single'][l]['b']))
+        for l in range(len(self.hidden_dims) - 1):
+            put(dev(params['double'][l]['w']))
+            put(dev(params['double'][l]['b']))
+        for c in range(nch):
+            ns = self.nelec[c]
+            nparam = ns * self.n_det
+            w = dev(params['orbital'][c]['w'])
+            off, rows, cols = self.blocks[3 * len(self.hidden_dims) + 2 * (len(self.hidden_dims) - 1) + 3 * c]
+            src = self._orbital_column_map(nparam, cols)
+            packed = torch.zeros(rows, cols, dtype=self.dtype, device=self.device)
+            valid = src >= 0
+            packed[:, torch.as_tensor(np.nonzero(valid)[0], device=self.device)] = \
+                w[:, torch.as_tensor(src[valid], device=self.device)]
+            put(packed)
+            put(dev(params['envelope'][c]['pi']))
+            put(dev(params['envelope'][c]['sigma']))
+        self._packed, self._packed_key = flat, key
+        return flat
+
+    def _orbital_column_map(self, nparam, cols):
+        """Packed column c -> reference column of orbital[s]['w'] (or -1 for padding).
+        Within every 16-column tile the MFMA accumulator gives one lane the rows
+        {q, q+4, q+8, q+12} (f64) or {4q..4q+3} (f32); they are assigned
+        (Re p, Im p, Re p+4, Im p+4) with p = 8*tile + q, so the complex product with the
+        envelope/phase jet is lane-local (kernel k_orbital)."""
+        src = -np.ones(cols, dtype=np.int64)
+        for c in range(cols):
+            t, o = divmod(c, 16)
+            if self.dtype == torch.float64:
+                q, r = o % 4, o // 4
+            else:
+                q, r = o // 4, o % 4
+            p = 8 * t + q + 4 * (r // 2)
+            if p < nparam:
+                src[c] = p + (r % 2) * nparam
+        return src
+
+    # ------------------------------------------------------------------ calls
+    def ewald(self, x):
+        x = self._check_x(x)
+        out = torch.empty(x.shape[0], 3, dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.ds_ewald(self.handle, _ptr(x), x.shape[0], _ptr(out), _stream()), 'ds_ewald')
+        return out
+
+    def local_energy(self, params, x, want_logpsi=False, ws_bytes=None):
+        x = self._check_x(x)
+        B = x.shape[0]
+        p = self.pack_params(params)
+        ws = self.workspace(B, ws_bytes)
+        ke = torch.empty(B, 2, dtype=self.dtype, device=self.device)
+        ew = torch.empty(B, dtype=self.dtype, device=self.device)
+        la = torch.empty(B, dtype=self.dtype, device=self.device) if want_logpsi else None
+        ph = torch.empty(B, 2, dtype=self.dtype, device=self.device) if want_logpsi else None
+        _lib.check(self.lib.ds_local_energy(self.handle, _ptr(p), _ptr(x), B, _ptr(ke), _ptr(ew), _ptr(la), _ptr(ph),
+                                            _ptr(ws), ws.numel(), _stream()), 'ds_local_energy')
+        return ke, ew, la, ph
+
+    def logpsi(self, params, x, ws_bytes=None):
+        x = self._check_x(x)
+        B = x.shape[0]
+        p = self.pack_params(params)
+        ws = self.workspace(B, ws_bytes)
+        la = torch.empty(B, dtype=self.dtype, device=self.device)
+        ph = torch.empty(B, 2, dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.ds_logpsi(self.handle, _ptr(p), _ptr(x), B, _ptr(la), _ptr(ph), _ptr(ws), ws.numel(),
+                                      _stream()), 'ds_logpsi')
+        return la, ph
+
+    def orbitals(self, params, x):
+        x = self._check_x(x)
+        B = x.shape[0]
+        p = self.pack_params(params)
+        ws = self.workspace(B)
+        outs = [torch.empty(B, self.n_det, ns, ns, 2, dtype=self.dtype, device=self.device) if ns else None
+                for ns in self.nelec]
+        _lib.check(self.lib.ds_orbitals(self.handle, _ptr(p), _ptr(x), B, _ptr(outs[0]), _ptr(outs[1]), _ptr(ws),
+                                        ws.numel(), _stream()), 'ds_orbitals')
+        return [torch.view_as_complex(o) for o in outs if o is not None]
+
+    def mh_propose(self, x1, normal, width):
+        x1 = self._check_x(x1)
+        normal = self._check_x(normal)
+        x2 = torch.empty_like(x1)
+        _lib.check(self.lib.ds_mh_propose(self.handle, _ptr(x1), _ptr(normal), float(width), x1.shape[0], _ptr(x2),
+                                          _stream()), 'ds_mh_propose')
+        return x2
+
+    def mh_accept(self, x1, lp1, x2, lp2, uniform, n_accept):
+        """In-place select on x1 / lp1; n_accept (1,) is incremented."""
+        _lib.check(self.lib.ds_mh_accept(self.handle, _ptr(x1), _ptr(lp1), _ptr(x2), _ptr(lp2), _ptr(uniform),
+                                         x1.shape[0], _ptr(n_accept), _stream()), 'ds_mh_accept')
+
+    def debug_stage(self, params, x, stage, n_elems):
+        x = self._check_x(x)
+        p = self.pack_params(params)
+        ws = self.workspace(x.shape[0])
+        out = torch.zeros(int(n_elems), dtype=self.dtype, device=self.device)
+        n = self.lib.ds_debug_stage(self.handle, _ptr(p), _ptr(x), x.shape[0], stage.encode(), _ptr(out), out.numel(),
+                                    _ptr(ws), ws.numel(), _stream())
+        if n < 0:
+            raise RuntimeError(f'ds_debug_stage({stage}): {self.lib.ds_last_error().decode()}')
+        return out[:n]

@@ -1,0 +1,167 @@
+/*
+ * deepsolid_hip.h -- C ABI of libdeepsolid_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the VMC inner loop of bytedance/DeepSolid.  The reference
+ * has no FFI layer: the boundary is three Python factories whose closures are
+ * consumed by process.py / train.py.  Each entry point below names the reference
+ * function(s) whose arithmetic it replaces; the Python side
+ * (deepsolid_amd/{network,hamiltonian,qmc,ewaldsum,distance}.py) keeps the
+ * reference signatures and calls these through ctypes with raw device pointers.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; ds_last_error()
+ *     returns a thread-local message for the last failure;
+ *   - all `const void*` / `void*` data arguments are DEVICE pointers owned by the
+ *     caller (torch tensors), element type given by ds_system_desc.dtype
+ *     (0 = float64, 1 = float32); walkers are (B, 3*N) row-major, B = batch;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); nothing is
+ *     allocated or synchronised after ds_system_create; calls on distinct streams
+ *     with distinct workspaces are independent;
+ *   - no torch types appear anywhere in this interface.
+ */
+#ifndef DEEPSOLID_HIP_H
+#define DEEPSOLID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_MAX_LAYERS 8
+#define DS_MAX_SYM 6 /* rows of AV/BV: 3 ('minimal'), 4 (fcc/hexagonal), 6 (bcc) -- supercell.py:98-140 */
+
+typedef struct ds_system ds_system; /* opaque handle, one per device */
+
+/* Host-side description of one simulation cell + network architecture.  All
+ * pointers are HOST pointers to float64 / int data and are copied by
+ * ds_system_create.  Field provenance (reference file:line):
+ *   n_up,n_dn            simulation_cell.nelec                      network.py:644
+ *   prim_* / sim_*       simulation_cell.original_cell.a/.AV/.BV,
+ *                        simulation_cell.a/.AV/.BV                  network.py:281-296
+ *   prim_atoms           original_cell.atom_coords()                network.py:643
+ *   klist_up/dn          hf.SCF.klist                               hf.py:84-104
+ *   hidden_single/double, n_det, ...  cfg.network.detnet            base_config.py:129-139
+ *   ewald_*              EwaldSum.__init__ products                 ewaldsum.py:34-136
+ *   dist_mode            MinimalImageDistance dispatch              distance.py:43-61
+ */
+typedef struct ds_system_desc {
+    int32_t dtype;               /* 0 = f64, 1 = f32 */
+    int32_t n_up, n_dn;
+    int32_t n_atoms_prim;
+    const double* prim_atoms;    /* (n_atoms_prim, 3) */
+    double prim_a[9];
+    double sim_a[9];
+    int32_t n_sym;               /* rows of AV/BV */
+    double prim_AV[DS_MAX_SYM * 3], prim_BV[DS_MAX_SYM * 3];
+    double sim_AV[DS_MAX_SYM * 3], sim_BV[DS_MAX_SYM * 3];
+    /* network */
+    int32_t n_layers;            /* len(hidden_dims) */
+    int32_t hidden_single[DS_MAX_LAYERS];
+    int32_t hidden_double[DS_MAX_LAYERS];
+    int32_t n_det;               /* determinants */
+    int32_t distance_type;       /* 0 = 'nu' (network.py:207); others rejected */
+    int32_t envelope_type;       /* 0 = 'isotropic' (network.py:335); others rejected */
+    int32_t full_det;            /* 0 (block-diagonal, base_config default); 1 rejected */
+    int32_t use_last_layer;      /* 0; 1 rejected */
+    int32_t bias_orbitals;       /* 0; 1 rejected */
+    const double* klist_up;      /* (n_up, 3) */
+    const double* klist_dn;      /* (n_dn, 3) */
+    /* Ewald tables */
+    int32_t n_atoms_sim;
+    const double* sim_atoms;     /* (n_atoms_sim, 3) */
+    const double* sim_charges;   /* (n_atoms_sim,) */
+    int32_t dist_mode;           /* 0 diagonal, 1 orthogonal, 2 general */
+    int32_t n_g;
+    const double* gpoints;       /* (n_g, 3) */
+    const double* gweight;       /* (n_g,) */
+    const double* ion_exp_re;    /* (n_g,)  Re sum_a Z_a exp(i G.R_a) */
+    const double* ion_exp_im;    /* (n_g,) */
+    double ewald_alpha;
+    double ee_const;             /* EwaldSum.ee_const(N)   ewaldsum.py:109 */
+    double ei_const;             /* EwaldSum.ei_const(N)   ewaldsum.py:112 */
+    double ii_total;             /* ion_ion + ii_const     ewaldsum.py:190 */
+} ds_system_desc;
+
+/* Parameter buffer: one flat device array of `dtype` elements.  ds_param_layout
+ * reports, for the handle's architecture, the element offset and the logical
+ * (rows, cols) of every block in this order:
+ *   for l in layers:  W_loc_l  [(h1_in + nch*h2_in), h1_out]   rows: h_i | mean_j h2_ij (up) | (dn)
+ *                     W_sh_l   [(nch*h1_in), h1_out]           rows: mean_up h | mean_dn h
+ *                     b_l      [1, h1_out]
+ *   for l in double layers: W2_l [h2_in, h2_out], b2_l [1, h2_out]
+ *   for s in active spins:  W_orb_s [h1_last, 2*n_s*n_det]  (columns re/im interleaved in
+ *                           groups of 4: see deepsolid_amd/network.py pack_params)
+ *                           pi_s [A, n_s*n_det], sigma_s [A, n_s*n_det]
+ * i.e. the rows of the reference's `single[l]['w']` (network.py:126-158) split
+ * into the per-electron and the shared (spin-mean) part. */
+typedef struct ds_param_block {
+    int64_t offset;
+    int32_t rows, cols;
+} ds_param_block;
+
+int ds_system_create(const ds_system_desc* desc, ds_system** out);
+void ds_system_destroy(ds_system* sys);
+const char* ds_last_error(void);
+
+int64_t ds_param_count(const ds_system* sys);
+/* fills up to `max_blocks` entries, returns the number of blocks */
+int ds_param_layout(const ds_system* sys, ds_param_block* blocks, int max_blocks);
+
+/* bytes of scratch the calls below need for a batch of B walkers */
+int64_t ds_workspace_bytes(const ds_system* sys, int64_t B);
+
+/* network.eval_func (network.py:563-606), methods eval_phase_and_slogdet /
+ * eval_slogdet / eval_logdet, batched as process.py:116-118 vmaps it.
+ * out_logabs (B,), out_phase (B,2) = (Re, Im) of the unit phase; either may be NULL. */
+int ds_logpsi(ds_system* sys, const void* params, const void* x, int64_t B,
+              void* out_logabs, void* out_phase, void* ws, int64_t ws_bytes, void* stream);
+
+/* network.eval_func method 'eval_mats' (network.py:601): out_up (B, n_det, n_up, n_up, 2),
+ * out_dn (B, n_det, n_dn, n_dn, 2), complex as (Re, Im) pairs. */
+int ds_orbitals(ds_system* sys, const void* params, const void* x, int64_t B,
+                void* out_up, void* out_dn, void* ws, int64_t ws_bytes, void* stream);
+
+/* ewaldsum.EwaldSum.energy (ewaldsum.py:185-191): out (B,3) = (ee, ei, ii). */
+int ds_ewald(ds_system* sys, const void* x, int64_t B, void* out, void* stream);
+
+/* hamiltonian.local_energy_seperate (hamiltonian.py:194-228), all Laplacian modes
+ * (for / dim_batch / hessian / partition return the same numbers and map to one
+ * forward-Laplacian kernel chain).  out_ke (B,2) = complex kinetic energy,
+ * out_ewald (B,) = ee+ei+ii; out_logabs (B,) / out_phase (B,2) optional (NULL). */
+int ds_local_energy(ds_system* sys, const void* params, const void* x, int64_t B,
+                    void* out_ke, void* out_ewald, void* out_logabs, void* out_phase,
+                    void* ws, int64_t ws_bytes, void* stream);
+
+/* distance.enforce_pbc (distance.py:144-163), batched over B*N electrons; needs no handle.
+ * latvec: HOST pointer to the 3x3 lattice (rows = lattice vectors); dtype 0 = f64, 1 = f32;
+ * x, out_x: (n_elec, 3) device arrays; out_wrap (n_elec, 3) device array or NULL. */
+int ds_enforce_pbc(const double* latvec, int dtype, const void* x, int64_t n_elec, void* out_x,
+                   void* out_wrap, void* stream);
+
+/* qmc.mh_update symmetric branch (qmc.py:190-196, 217-222) split around the network call:
+ *   propose: x2 = wrap(x1 + width * normal)
+ *   accept : cond = (lp2 - lp1) > log(uniform); x1,lp1 <- select; n_accept[0] += sum(cond)
+ * `normal` (B,3N) and `uniform` (B,) are caller-supplied noise (torch Philox on device). */
+int ds_mh_propose(ds_system* sys, const void* x1, const void* normal, double width, int64_t B,
+                  void* x2, void* stream);
+int ds_mh_accept(ds_system* sys, void* x1, void* lp1, const void* x2, const void* lp2,
+                 const void* uniform, int64_t B, void* n_accept, void* stream);
+
+/* Stage dumps for parity tests (tests only; sizes documented in DESIGN.md).
+ * Runs the forward-Laplacian chain for the first walkers of the batch and copies
+ * the named intermediate into `out` (device, dtype elements).  Returns elements written. */
+int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_t B,
+                       const char* stage, void* out, int64_t out_elems,
+                       void* ws, int64_t ws_bytes, void* stream);
+
+/* fp64 MFMA issue-rate micro-benchmark used by bench.py to confirm the roofline peak:
+ * runs `iters` dependent-free v_mfma_f64_16x16x4_f64 per wave on every SIMD, returns
+ * FLOPs executed; the caller times it with HIP events. */
+int64_t ds_mfma_f64_peak(int64_t iters, void* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPSOLID_HIP_H */

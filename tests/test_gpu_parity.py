@@ -1,0 +1,195 @@
+"""GPU parity tests: every stage of the HIP kernel chain against the CPU oracle and the
+golden vectors executed from the reference (through the C ABI, deepsolid_amd.device).
+
+Tolerances (float64): forward quantities 1e-10 absolute/relative, local energies 1e-8 Ha
+(north star: 1e-6 Ha)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ewaldsum as oewald
+from oracle import forward_laplacian as ofl
+from oracle import hamiltonian as oham
+from oracle import network as onet
+
+from common import load_case, oracle_net, tt
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_params(params):
+    return {k: [{kk: torch.as_tensor(vv, dtype=torch.float64, device='cuda') for kk, vv in d.items()} for d in v]
+            for k, v in params.items()}
+
+
+def system_for(cell, klist, net_kw):
+    from deepsolid_amd.device import DeviceSystem
+    return DeviceSystem.for_network(cell, klist, net_kw, torch.float64)
+
+
+def dims(sysd):
+    N = sysd.n
+    D = 3 * N + 2
+    P = (D + 15) // 16 * 16
+    NP = (N * N + 15) // 16 * 16
+    A = np.asarray(sysd.cell.original_cell.atom_coords()).reshape(-1, 3).shape[0]
+    nch = 2 if sysd.nelec[1] else 1
+    h1 = [4 * A] + [h[0] for h in sysd.hidden_dims]
+    h2 = [4] + [h[1] for h in sysd.hidden_dims]
+    ldk = max(max(h1[l] + nch * h2[l] for l in range(len(sysd.hidden_dims))), h1[-1])
+    return N, D, P, NP, A, nch, h1, h2, ldk
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_2x1x1', 'bcc_li', 'graphene', 'diamond'])
+def test_ewald_vs_reference_vectors(name):
+    fx, cell, klist, net_kw, params = load_case(name)
+    from deepsolid_amd.ewaldsum import EwaldSum
+    ew = EwaldSum(cell)
+    # host tables vs the reference-executed ones
+    assert ew.gpoints.shape[0] == int(fx['ewald_ng'])
+    assert abs(ew.alpha - float(fx['ewald_alpha'])) < 1e-13
+    assert ew.dist_mode == int(fx['dist_mode'])
+    assert abs(ew.ion_ion - float(fx['ewald_ion_ion'])) < 1e-10
+    x = torch.as_tensor(fx['x'], device='cuda')
+    ee, ei, ii = ew.energy(x)
+    got = torch.stack([ee, ei, ii], -1).cpu().numpy()
+    np.testing.assert_allclose(got, fx['ewald'], atol=5e-10)
+    e1 = ew.energy(x[0])
+    np.testing.assert_allclose([float(v) for v in e1], fx['ewald'][0], atol=5e-10)
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'bcc_li', 'graphene'])
+def test_wrap_vs_reference_vectors(name):
+    fx, cell, _, _, _ = load_case(name)
+    from deepsolid_amd import distance
+    wx, wrap = distance.enforce_pbc(cell.a, torch.as_tensor(fx['x'], device='cuda'))
+    np.testing.assert_allclose(wx.cpu().numpy(), fx['pbc_x'], atol=1e-11)
+    np.testing.assert_array_equal(wrap.cpu().numpy(), fx['pbc_wrap'])
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li'])
+def test_stages_vs_forward_laplacian_oracle(name):
+    """Every intermediate jet tensor of the chain for 2 walkers."""
+    fx, cell, klist, net_kw, params = load_case(name)
+    sysd = system_for(cell, klist, net_kw)
+    N, D, P, NP, A, nch, h1, h2, ldk = dims(sysd)
+    B = 2
+    x = torch.as_tensor(fx['x'][:B], device='cuda')
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    st = [ofl.stages(p_cpu, tt(fx['x'][b]), klist, cell, net_kw) for b in range(B)]
+    nl = len(sysd.hidden_dims)
+    tol = 2e-10
+
+    def G(stage):
+        return sysd.debug_stage(dp, x, stage, B * N * ldk * P).cpu().numpy().reshape(B, N, ldk, P)
+
+    def H2(stage, k2):
+        return sysd.debug_stage(dp, x, stage, B * k2 * 5 * NP).cpu().numpy().reshape(B, k2, 5, NP)
+
+    def dense_h2(h, b):
+        """(k2,5,NP) pair jets -> dense (N,N,k2,D) like the oracle."""
+        k2 = h.shape[0]
+        out = np.zeros((N, N, k2, D))
+        hp = h[:, :, :N * N].reshape(k2, 5, N, N)
+        out[..., 0] = hp[:, 0].transpose(1, 2, 0)
+        out[..., 1] = hp[:, 4].transpose(1, 2, 0)
+        for i in range(N):
+            for j in range(N):
+                if i != j:
+                    out[i, j, :, 2 + 3 * i:5 + 3 * i] = hp[:, 1:4, i, j]
+                    out[i, j, :, 2 + 3 * j:5 + 3 * j] = -hp[:, 1:4, i, j]
+        return out
+
+    for l in range(nl + 1):
+        g = G(f'g{l}')
+        for b in range(B):
+            ref = st[b][f'h1_{l}'].numpy()                         # (N, K, D)
+            assert rel_err(g[b, :, :h1[l], :D], ref) < tol, f'h1_{l}'
+            assert np.abs(g[b, :, :h1[l], D:]).max() == 0.0
+            if l < nl:
+                # rows h1..: spin means of the pair stream over its first electron index
+                h2o = st[b][f'h2_{l}'].numpy()                     # (N,N,k2,D)
+                off = 0
+                for s, ns in enumerate(sysd.nelec):
+                    if ns == 0:
+                        continue
+                    sl = slice(0, sysd.nelec[0]) if s == 0 else slice(sysd.nelec[0], N)
+                    refm = h2o[sl].mean(0)                         # (N,k2,D)
+                    got = g[b, :, h1[l] + off:h1[l] + off + h2[l], :D]
+                    assert rel_err(got, refm) < tol, f'm2_{l}_{s}'
+                    off += h2[l]
+        if l < nl:
+            hh = H2(f'h2_{l}', h2[l])
+            for b in range(B):
+                assert rel_err(dense_h2(hh[b], b), st[b][f'h2_{l}'].numpy()) < tol, f'h2_{l}'
+    # orbital matrices with all slots
+    mo = sysd.debug_stage(dp, x, 'mout', B * sum(sysd.n_det * ns * ns * 2 * P for ns in sysd.nelec)).cpu().numpy()
+    per = sum(sysd.n_det * ns * ns * 2 * P for ns in sysd.nelec)
+    mo = mo.reshape(B, per)
+    for b in range(B):
+        off = 0
+        for s, ns in enumerate(sysd.nelec):
+            if ns == 0:
+                continue
+            m = mo[b, off:off + sysd.n_det * ns * ns * 2 * P].reshape(sysd.n_det, ns, ns, 2, P)
+            got = m[..., 0, :D] + 1j * m[..., 1, :D]
+            ref = st[b]['mats'][s].numpy()
+            assert rel_err(got, ref) < tol, f'mats_{s}'
+            off += sysd.n_det * ns * ns * 2 * P
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist'])
+def test_logpsi_and_orbitals_vs_reference_vectors(name):
+    from deepsolid_amd import network
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    x = torch.as_tensor(fx['x'], device='cuda')
+    net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_phase_and_slogdet', **net_kw)
+    phase, logabs = net.apply(dp, x)
+    np.testing.assert_allclose(logabs.cpu().numpy(), fx['logabs'], atol=1e-9)
+    np.testing.assert_allclose(phase.cpu().numpy(), fx['phase'], atol=1e-8)
+    mats = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_mats', **net_kw).apply(dp, x)
+    for s, m in enumerate(mats):
+        ref = fx[f'orbitals_{s}']
+        assert rel_err(m.cpu().numpy(), ref) < 1e-10
+    # single-walker call and the other methods
+    ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw).apply(dp, x[1])
+    assert abs(ld.real.item() - fx['logabs'][1]) < 1e-9
+    assert abs(np.exp(1j * ld.imag.item()) - fx['phase'][1]) < 1e-8
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist'])
+def test_local_energy_vs_oracle(name):
+    from deepsolid_amd import hamiltonian, network
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    x = torch.as_tensor(fx['x'], device='cuda')
+    net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    for mode in ('for', 'hessian', 'dim_batch', 'partition'):
+        ke, ew = hamiltonian.local_energy_seperate(net.apply, cell, mode=mode, partition_number=3 if (3 * sum(cell.nelec)) % 3 == 0 else 2)(dp, x)
+    ke, ew = ke.cpu().numpy(), ew.cpu().numpy()
+    onet_ = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    mode = 'for' if sum(cell.nelec) <= 8 else 'hessian'
+    el = oham.local_energy_seperate(onet_.apply, cell, mode=mode)
+    for b in range(min(2, x.shape[0])):
+        k_ref, e_ref = el(p_cpu, tt(fx['x'][b]))
+        assert abs(ke[b] - complex(k_ref)) < 1e-8 * max(1.0, abs(complex(k_ref))), (ke[b], complex(k_ref))
+        assert abs(ew[b] - float(e_ref)) < 1e-9
+    # the rest of the batch against the forward-Laplacian restatement
+    for b in range(2, x.shape[0]):
+        k_ref = complex(ofl.stages(p_cpu, tt(fx['x'][b]), klist, cell, net_kw)['ke'])
+        assert abs(ke[b] - k_ref) < 1e-8 * max(1.0, abs(k_ref))
+    np.testing.assert_allclose(ew, fx['ewald'].sum(-1), atol=1e-9)
+    # FD of the reference-executed forward (gross-error pin)
+    if 'ke_fd' in fx:
+        for b in range(len(fx['ke_fd'])):
+            assert abs(ke[b] - fx['ke_fd'][b]) < 10 * float(fx['ke_fd_tol']) * max(1.0, abs(ke[b]))
+    with pytest.raises(ValueError):
+        hamiltonian.local_energy_seperate(net.apply, cell, mode='nope')
