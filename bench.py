@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Headline benchmark: local-energy evaluations per second (BASELINE.json metric).
+
+One "step" = one primal pass of train.make_loss.total_energy (reference train.py:67-89) over a
+batch of synthetic walkers already resident in HBM: kinetic energy (forward-Laplacian HIP chain)
++ Ewald energy per walker, batch mean / variance, and -- for N > 1 -- the packed RCCL all-reduce
+that replaces the reference's pmean (train.py:78-80).  Walkers shard across ranks with no other
+communication ("scaling": "weak": every rank keeps `--batch` walkers).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torchrun)
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the
+library over the timed region) and `cpu_baseline` (the oracle's reference-algorithm restatement,
+timed on this box's host cores; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {torch.float64: 78.6, torch.float32: 157.3}   # MI355X dense matrix = vector peak (datasheet)
+
+
+def layer_flops(n_elec, kloc, ksh, nout):
+    """Algorithmic FLOPs of one one-electron-stream layer per walker in the forward-Laplacian
+    formulation: D = 3N+2 jet slots per scalar; per-electron rows [h_i | m2_i] (kloc)
+    and the spin-mean rows shared by all electrons (ksh), multiply-add = 2."""
+    d = 3 * n_elec + 2
+    return 2.0 * n_elec * d * kloc * nout + 2.0 * d * ksh * nout
+
+
+def cpu_baseline(cell, klist, net_kw, params_np, x_np, seconds=20.0):
+    """Reference-algorithm CPU restatement (JAX unavailable): mode `for` of hamiltonian.py:45-70
+    + Ewald, one walker after another on all host cores, until ~`seconds` are spent."""
+    from oracle import forward_laplacian as ofl
+    from oracle import hamiltonian as oham
+    from oracle import network as onet
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    net = onet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    el = oham.local_energy_seperate(net.apply, cell, mode='for')
+    p = onet.params_to_torch(params_np)
+    el(p, torch.as_tensor(x_np[0]))                       # warm-up (also builds the Ewald tables)
+    t0 = time.perf_counter()
+    n = 0
+    vals = []
+    while n < x_np.shape[0] and (time.perf_counter() - t0 < seconds or n < 1):
+        ke, ew = el(p, torch.as_tensor(x_np[n]))
+        vals.append(complex(ke) + float(ew))
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit='local-energy evals/s', cores=cores, kind='port',
+                sample=f'{n} walkers of the same workload, reference mode `for` (2*3N jvp-of-grad sweeps) + Ewald, '
+                       f'torch CPU float64, {dt:.1f} s'), vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--system', default='bcc_li')
+    ap.add_argument('--batch', type=int, default=4096, help='walkers per GPU')
+    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from deepsolid_amd import network, systems, train
+    dtype = torch.float64 if args.dtype == 'f64' else torch.float32
+    cell, klist = systems.build(args.system)
+    net_kw = dict(systems.DETNET_DEFAULTS)
+    net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', dtype=dtype, **net_kw)
+    params = net.init(0)                                   # numpy default_rng(0), identical on every rank
+    x_np = systems.synthetic_walkers(cell, args.batch, seed=1234 + rank)
+    x = torch.as_tensor(x_np, dtype=dtype, device=dev)
+    total_energy = train.make_loss(net.apply, None, cell)
+    sysd = net.apply.system
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, aux = total_energy(params, x)
+    sync()
+    sysd.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, aux = total_energy(params, x)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = sysd.profile_read()
+    sysd.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_e = sum(cell.nelec)
+    h1 = net_kw['hidden_dims'][0][0]
+    h2 = net_kw['hidden_dims'][0][1]
+    nch = 2 if cell.nelec[1] else 1
+    f_layer = layer_flops(n_e, h1 + nch * h2, nch * h1, h1)
+    ms_hidden, n_launch = prof['single_hidden']
+    n_hidden = len(net_kw['hidden_dims']) - 1
+    flops_total = f_layer * args.batch * n_hidden * args.steps           # this rank, timed region
+    achieved = flops_total / (ms_hidden * 1e-3) / 1e12 if ms_hidden > 0 else 0.0
+    peak = PEAK_TFLOPS[dtype]
+    out = {
+        'metric': 'local-energy evals/sec', 'value': world * args.batch * args.steps / dt,
+        'unit': 'local-energy evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': f'{args.system} {n_e} e- ({cell.nelec[0]},{cell.nelec[1]}), total_energy primal '
+                               f'(E_kin forward-Laplacian + Ewald), default detnet ((256,32),)*3, 8 dets',
+                   'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': f'walker-dp{world}'},
+        'energy_mean_ha': float(loss), 'energy_imag_ha': float(aux.imaginary), 'variance': float(aux.variance),
+        'roofline': {'bound': 'mfma', 'kernel': 'k_single_layer (hidden one-electron layers, K=%d+%d shared)' % (h1 + nch * h2, nch * h1),
+                     'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                     'traffic': None, 'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch,
+                     'flops_per_walker_layer': f_layer},
+        'kernel_ms_per_step': {k: v[0] / args.steps for k, v in prof.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        params_np = {k: [{kk: vv.cpu().numpy() for kk, vv in d.items()} for d in v] for k, v in params.items()}
+        cb, ref_vals = cpu_baseline(cell, klist, net_kw, params_np, x_np, args.cpu_seconds)
+        out['cpu_baseline'] = cb
+        e_gpu = aux.local_energy[:len(ref_vals)].cpu().numpy()
+        out['max_abs_err_ha'] = float(np.abs(e_gpu - np.asarray(ref_vals)).max())
+        out['speedup_vs_cpu_baseline'] = out['value'] / cb['value']
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

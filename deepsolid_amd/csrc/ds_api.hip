@@ -64,9 +64,28 @@ struct ds_system {
     WsLayout ws;
     // block indices
     std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_pi, i_sg;
+    // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[DS_PROF_KINDS];
+    std::vector<hipEvent_t> prof_pool;
 };
 
 namespace {
+
+// records an event pair around the launches issued while it is alive
+struct ProfScope {
+    ds_system* s; int kind; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+    static hipEvent_t get(ds_system* s) {
+        if (!s->prof_pool.empty()) { hipEvent_t e = s->prof_pool.back(); s->prof_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    ProfScope(ds_system* s_, int kind_, hipStream_t st_) : s(s_), kind(kind_), st(st_) {
+        if (s->prof_on) { e0 = get(s); e1 = get(s); (void)hipEventRecord(e0, st); }
+    }
+    ~ProfScope() {
+        if (e0) { (void)hipEventRecord(e1, st); s->prof_ev[kind].push_back({e0, e1}); }
+    }
+};
 
 template <typename T>
 void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::vector<T>& host) {
@@ -260,6 +279,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     const int stop = dr ? dr->stop : STOP_NONE;
     // 1. features
     {
+        ProfScope ps(s, DS_PROF_FEATURES, st);
         size_t sh = (size_t)(9 * S.N) * sizeof(T) + (size_t)S.N * S.A * 4 * sizeof(ds::Jet5<T>);
         hipLaunchKernelGGL((ds::k_features<T>), dim3((unsigned)Bc), dim3(256), sh, st, S, x, blk(s->i_pi[0]), blk(s->i_sg[0]),
                            blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), c.G[0], c.MEAN[0], c.H2[0], c.Q);
@@ -271,8 +291,11 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
         // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
-        hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc), dim3(256), (size_t)S.nch * K2 * 5 * sizeof(T), st, S,
-                           c.H2[hi], K2, c.G[gi], Kh);
+        {
+            ProfScope ps(s, DS_PROF_M2_EXPAND, st);
+            hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc), dim3(256), (size_t)S.nch * K2 * 5 * sizeof(T), st, S,
+                               c.H2[hi], K2, c.G[gi], Kh);
+        }
         if (stop == STOP_G0 + l) return copy_out(dr, c.G[gi], L.G * Bc, st);
         // pair stream layer
         if (l < S.n_double) {
@@ -282,6 +305,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             dim3 grid((S.NP / 16 + 3) / 4, (unsigned)Bc);
             const bool res = K2 == K2o;
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
+            ProfScope ps(s, DS_PROF_TWO_LAYER, st);
 #define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES>), grid, dim3(256), 0, st, S, c.H2[hi], K2, W2, b2, c.H2[hi ^ 1])
             if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
             else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
@@ -291,11 +315,15 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         if (Nout % 64 || Nout > 256) return fail("hidden_single must be a multiple of 64 and <= 256 (got %d)", Nout);
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
         const bool res = Kh == Nout;
-        int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
+        int rc;
+        {
+        ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
+        rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             launch_single<T, NB, ST>(S, res, Bc, st, c.G[gi], c.G[gi ^ 1], blk(s->i_wloc[l]), blk(s->i_wsh[l]), blk(s->i_b[l]),
                                      c.MEAN[mi], c.MEAN[mi ^ 1], c.SB, Kloc, Ksh, Nout);
         });
+        }
         if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
         gi ^= 1; mi ^= 1;
         if (l < S.n_double) {
@@ -307,6 +335,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     if (stop == STOP_G0 + S.n_layers) return copy_out(dr, c.G[gi], L.G * Bc, st);
     // orbitals
     for (int sp = 0; sp < S.nch; ++sp) {
+        ProfScope ps(s, DS_PROF_ORBITAL, st);
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             dim3 grid(S.ocols[sp] / (16 * NB), (unsigned)Bc);
@@ -320,12 +349,14 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     for (int sp = 0; sp < S.nch; ++sp) {
         const int n = sp == 0 ? S.n_up : S.n_dn;
         size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
+        ProfScope ps(s, DS_PROF_DET_INVERSE, st);
         hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp,
                            c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp]);
     }
     if (stop == STOP_MINV) return copy_out(dr, c.MINV, L.MINV * Bc, st);
     for (int sp = 0; sp < S.nch; ++sp) {
         const int n = sp == 0 ? S.n_up : S.n_dn;
+        ProfScope ps(s, DS_PROF_DET_TRACE, st);
 #define DS_TRACE(NMAX, SP)                                                                                                    \
     do {                                                                                                                      \
         size_t sh = ((size_t)n * n + (size_t)SP * n * n + 256) * sizeof(ds::Cx<T>);                                             \
@@ -341,8 +372,11 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     }
     if (stop == STOP_DETS) return copy_out(dr, c.DETS, L.DETS * Bc, st);
     if (stop == STOP_TR) return copy_out(dr, c.TR, L.TR * Bc, st);
-    hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, c.TR, L.TR, L.tr_off[1], c.DETS, L.DETS,
-                       L.dets_off[1], out_ke, out_logabs, out_phase);
+    {
+        ProfScope ps(s, DS_PROF_COMBINE, st);
+        hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, c.TR, L.TR, L.tr_off[1], c.DETS, L.DETS,
+                           L.dets_off[1], out_ke, out_logabs, out_phase);
+    }
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -366,6 +400,7 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
         for (int64_t b0 = 0; b0 < B; b0 += chunk) {
             const int64_t Bc = std::min(chunk, B - b0);
             size_t sh = (size_t)(3 * S.N + 512) * sizeof(T);
+            ProfScope ps(s, DS_PROF_EWALD, st);
             hipLaunchKernelGGL((ds::k_ewald<T>), dim3((unsigned)Bc), dim3(256), sh, st, S, (const T*)x + b0 * 3 * S.N, tmp);
             hipLaunchKernelGGL((ds::k_sum3<T>), dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, tmp, Bc, (T*)out_ewald + b0);
         }
@@ -584,6 +619,32 @@ int64_t ds_debug_stage(ds_system* s, const void* params, const void* x, int64_t 
         written = dr.written;
     }
     return rc ? -1 : written;
+}
+
+int ds_profile_enable(ds_system* s, int on) {
+    if (!s) return fail("null argument");
+    for (auto& v : s->prof_ev) {
+        for (auto& p : v) { s->prof_pool.push_back(p.first); s->prof_pool.push_back(p.second); }
+        v.clear();
+    }
+    s->prof_on = on != 0;
+    return 0;
+}
+
+int ds_profile_read(ds_system* s, double* ms_total, int64_t* launches) {
+    if (!s || !ms_total || !launches) return fail("null argument");
+    for (int k = 0; k < DS_PROF_KINDS; ++k) {
+        double tot = 0;
+        for (auto& p : s->prof_ev[k]) {
+            HIP_OK(hipEventSynchronize(p.second));
+            float ms = 0;
+            HIP_OK(hipEventElapsedTime(&ms, p.first, p.second));
+            tot += ms;
+        }
+        ms_total[k] = tot;
+        launches[k] = (int64_t)s->prof_ev[k].size();
+    }
+    return 0;
 }
 
 int64_t ds_mfma_f64_peak(int64_t iters, void* scratch, void* stream) {

@@ -301,6 +301,18 @@ class DeviceSystem:
         _lib.check(self.lib.ds_mh_accept(self.handle, _ptr(x1), _ptr(lp1), _ptr(x2), _ptr(lp2), _ptr(uniform),
                                          x1.shape[0], _ptr(n_accept), _stream()), 'ds_mh_accept')
 
+    def profile(self, on=True):
+        """Start (and reset) / stop per-kernel HIP-event timing inside the library."""
+        _lib.check(self.lib.ds_profile_enable(self.handle, int(bool(on))), 'ds_profile_enable')
+
+    def profile_read(self):
+        """-> {kernel kind: (total ms, launches)} for the launches since profile(True)."""
+        n = len(_lib.PROF_KINDS)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        _lib.check(self.lib.ds_profile_read(self.handle, ms, cnt), 'ds_profile_read')
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(_lib.PROF_KINDS)}
+
     def debug_stage(self, params, x, stage, n_elems):
         x = self._check_x(x)
         p = self.pack_params(params)

@@ -156,6 +156,24 @@ int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_
                        const char* stage, void* out, int64_t out_elems,
                        void* ws, int64_t ws_bytes, void* stream);
 
+/* Per-kernel timing with HIP events recorded on the caller's stream around every launch of the
+ * local-energy chain (bench.py's roofline numbers).  ds_profile_enable(sys, 1) resets and starts,
+ * ds_profile_read synchronises the recorded events and returns, per kernel kind, the summed
+ * duration in ms and the number of launches (arrays of DS_PROF_KINDS entries). */
+#define DS_PROF_FEATURES 0
+#define DS_PROF_M2_EXPAND 1
+#define DS_PROF_TWO_LAYER 2
+#define DS_PROF_SINGLE_FIRST 3   /* one-electron layer 0 (K = 4A + 8) */
+#define DS_PROF_SINGLE_HIDDEN 4  /* one-electron hidden layers (K = 256 + 64): the dominant kernel */
+#define DS_PROF_ORBITAL 5
+#define DS_PROF_DET_INVERSE 6
+#define DS_PROF_DET_TRACE 7
+#define DS_PROF_COMBINE 8
+#define DS_PROF_EWALD 9
+#define DS_PROF_KINDS 10
+int ds_profile_enable(ds_system* sys, int on);
+int ds_profile_read(ds_system* sys, double* ms_total, int64_t* launches);
+
 /* fp64 MFMA issue-rate micro-benchmark used by bench.py to confirm the roofline peak:
  * runs `iters` dependent-free v_mfma_f64_16x16x4_f64 per wave on every SIMD, returns
  * FLOPs executed; the caller times it with HIP events. */
