@@ -22,10 +22,12 @@ def _im(f):
 
 
 # hamiltonian.py:45-70
-def local_kinetic_energy_real_imag(f):
+def local_kinetic_energy_real_imag(f, directions=None):
+    """`directions` (not in the reference) truncates the fori_loop to its first iterations; only
+    bench.py's bounded CPU-baseline timing uses it (the partial sum is not an energy)."""
     def _lapl_over_f(params, x):
-        ne = x.shape[-1]
-        eye = torch.eye(ne, dtype=x.dtype)
+        ne = x.shape[-1] if directions is None else min(int(directions), x.shape[-1])
+        eye = torch.eye(x.shape[-1], dtype=x.dtype)
         g_re = lambda y: grad(_re(f), argnums=1)(params, y)
         g_im = lambda y: grad(_im(f), argnums=1)(params, y)
         kr = torch.zeros((), dtype=x.dtype)
