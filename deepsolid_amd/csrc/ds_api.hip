@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/deepsolid_hip.h"
-#include "ds_kernels.h"
+#include "ds_gemm.h"
 
 namespace {
 
@@ -45,7 +45,7 @@ void inv3(const double* a, double* o) {
 
 // per-walker workspace carve, in elements
 struct WsLayout {
-    size_t G, MEAN, SB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
+    size_t G, MEAN, ZB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
     size_t mout_off[2], minv_off[2], dets_off[2], tr_off[2];
     size_t per_walker;                                     // total elements per walker
 };
@@ -189,7 +189,9 @@ void build_layouts(ds_system* s) {
     for (int l = 0; l <= S.n_layers; ++l) { h1max = std::max(h1max, S.h1[l]); h2max = std::max(h2max, S.h2[l]); }
     w.G = (size_t)S.N * S.ldk * S.P;
     w.MEAN = (size_t)S.nch * h1max * S.P;
-    w.SB = (size_t)h1max * S.P;
+    w.ZB = (size_t)h1max * S.P;                      // shared spin-mean term S of one layer
+    for (int c = 0; c < S.nch; ++c)                  // ... or the orbital GEMM output of one spin
+        w.ZB = std::max(w.ZB, (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * S.P);
     w.H2 = (size_t)h2max * 5 * S.NP;
     w.Q = (size_t)S.N * S.nparam_max * 10;
     size_t mo = 0, mi = 0, de = 0, tr = 0;
@@ -202,11 +204,11 @@ void build_layouts(ds_system* s) {
         tr += (size_t)S.K * 2 * S.P;
     }
     w.MOUT = mo; w.MINV = rup((int)mi, 16); w.DETS = rup((int)de, 16); w.TR = tr;
-    w.per_walker = 2 * w.G + 2 * w.MEAN + w.SB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR;
+    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR;
 }
 
 template <typename T> struct Carve {
-    T *G[2], *MEAN[2], *SB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR;
+    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR;
 };
 template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     const WsLayout& w = s->ws;
@@ -214,7 +216,7 @@ template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     Carve<T> c;
     c.G[0] = p; p += w.G * Bc; c.G[1] = p; p += w.G * Bc;
     c.MEAN[0] = p; p += w.MEAN * Bc; c.MEAN[1] = p; p += w.MEAN * Bc;
-    c.SB = p; p += w.SB * Bc;
+    c.ZB = p; p += w.ZB * Bc;
     c.H2[0] = p; p += w.H2 * Bc; c.H2[1] = p; p += w.H2 * Bc;
     c.Q = p; p += w.Q * Bc;
     c.MOUT = p; p += w.MOUT * Bc;
@@ -225,18 +227,6 @@ template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
 }
 
 // ---------------------------------------------------------------- launch helpers
-template <typename T, int NB, int ST>
-void launch_single(const ds::SysDev<T>& S, bool res, int64_t Bc, hipStream_t st, const T* Gin, T* Gout, const T* Wloc,
-                   const T* Wsh, const T* b, const T* Min, T* Mout, T* SB, int Kloc, int Ksh, int Nout) {
-    dim3 grid((unsigned)Bc), block(Nout / (16 * NB) * 64);
-    if (res)
-        hipLaunchKernelGGL((ds::k_single_layer<T, NB, ST, true>), grid, block, 0, st, S, Gin, Gout, Wloc, Wsh, b, Min, Mout, SB,
-                           Kloc, Ksh, Nout);
-    else
-        hipLaunchKernelGGL((ds::k_single_layer<T, NB, ST, false>), grid, block, 0, st, S, Gin, Gout, Wloc, Wsh, b, Min, Mout, SB,
-                           Kloc, Ksh, Nout);
-}
-
 template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
     // (NB, ST): 16*NB output features x 16*ST slots per wave; accumulators = NB*ST tiles
     switch (st_tiles) {
@@ -311,19 +301,35 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
 #undef DS_TWO
         }
-        // one-electron stream layer
-        if (Nout % 64 || Nout > 256) return fail("hidden_single must be a multiple of 64 and <= 256 (got %d)", Nout);
+        // one-electron stream layer: GEMM over the N electron tiles + the shared spin-mean tile, then epilogue
+        if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
         const bool res = Kh == Nout;
-        int rc;
-        {
-        ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
-        rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
+        int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
-            launch_single<T, NB, ST>(S, res, Bc, st, c.G[gi], c.G[gi ^ 1], blk(s->i_wloc[l]), blk(s->i_wsh[l]), blk(s->i_b[l]),
-                                     c.MEAN[mi], c.MEAN[mi ^ 1], c.SB, Kloc, Ksh, Nout);
+            const dim3 block(Nout / (16 * NB) * 64);
+            const size_t gws = (size_t)S.N * S.ldk * S.P, gts = (size_t)S.ldk * S.P;
+            {
+                ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
+                // shared spin-mean term S (one tile per walker), then the N electron tiles with the fused epilogue
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(1, (unsigned)Bc), block, 0, st, (const T*)nullptr, (size_t)0,
+                                   (size_t)0, (const T*)nullptr, 0, c.MEAN[mi], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0, c.ZB,
+                                   (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, (const T*)nullptr);
+                if (res)
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N, (unsigned)Bc), block, 0, st, c.G[gi], gws, gts,
+                                       blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
+                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]));
+                else
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N, (unsigned)Bc), block, 0, st, c.G[gi], gws, gts,
+                                       blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
+                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]));
+            }
+            if (l + 1 < S.n_layers) {
+                ProfScope ps(s, DS_PROF_LAYER_EPILOGUE, st);
+                hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)(((size_t)Nout * S.P + 255) / 256), S.nch, (unsigned)Bc),
+                                   dim3(256), 0, st, S, c.G[gi ^ 1], c.MEAN[mi ^ 1], Nout);
+            }
         });
-        }
         if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
         gi ^= 1; mi ^= 1;
         if (l < S.n_double) {
@@ -333,14 +339,22 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         if (stop == STOP_MEAN1 && l == 0) return copy_out(dr, c.MEAN[mi], (size_t)S.nch * Nout * S.P * Bc, st);
     }
     if (stop == STOP_G0 + S.n_layers) return copy_out(dr, c.G[gi], L.G * Bc, st);
-    // orbitals
+    // orbitals: GEMM over the electrons of one spin, then envelope/phase product rule
     for (int sp = 0; sp < S.nch; ++sp) {
-        ProfScope ps(s, DS_PROF_ORBITAL, st);
+        const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp], Kh = S.h1[S.n_layers];
+        if (OC > 1024) return fail("2 * n_s * n_det = %d orbital columns exceed 1024", OC);
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
-            dim3 grid(S.ocols[sp] / (16 * NB), (unsigned)Bc);
-            hipLaunchKernelGGL((ds::k_orbital<T, NB, ST>), grid, dim3(64), 0, st, S, c.G[gi], blk(s->i_worb[sp]), c.Q, c.MOUT, sp,
-                               L.MOUT, L.mout_off[sp]);
+            {
+                ProfScope ps(s, DS_PROF_ORBITAL, st);
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(ns, (unsigned)Bc), dim3(OC / (16 * NB) * 64), 0, st,
+                                   c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
+                                   blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, c.ZB,
+                                   (size_t)ns * OC * S.P, OC, S.P, (const T*)nullptr, (const T*)nullptr);
+            }
+            ProfScope ps(s, DS_PROF_ORBITAL_EPILOGUE, st);
+            hipLaunchKernelGGL((ds::k_orbital_epilogue<T, ST>), dim3(ns, (unsigned)Bc), dim3(256), 0, st, S, c.ZB,
+                               (size_t)ns * OC * S.P, c.Q, c.MOUT, sp, L.MOUT, L.mout_off[sp]);
         });
         if (rc) return fail("no orbital kernel instance for %d slot tiles", S.P / 16);
     }

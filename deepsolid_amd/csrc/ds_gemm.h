@@ -1,0 +1,262 @@
+// ds_gemm.h -- the dense contraction of the chain and its element-wise epilogues.
+//
+//   k_jet_gemm        Z[tile][n][slot] = sum_k W[k][n] * X[tile][k][slot]      (fp64/fp32 MFMA)
+//   k_layer_epilogue  h_i <- res(h_i, tanh-jet(Z_i + S)) and the spin means of the new h
+//   k_orbital_epilogue  M = (Re,Im)(Phi) * q  with the product rule on the jets
+//
+// The GEMM is kept free of any epilogue arithmetic so that it needs only its accumulators and
+// two k-steps of operands in registers (two waves per SIMD); everything latency-sensitive
+// (tanh chain rule, residual, means) runs in a separate bandwidth-bound kernel with many waves.
+#pragma once
+#include "ds_kernels.h"
+
+namespace ds {
+
+// One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x all Nout
+// output features; wave w owns features [16*NB*w, 16*NB*(w+1)).  Tiles 0..n_tiles-1 use (X, W, K);
+// the optional extra tile (blockIdx.x == n_tiles) uses (X2, W2, K2): the shared spin-mean term.
+//   X  : [walker][tile][ldx rows][P]      W : [K][Nout]      Z : [walker][tile (+1)][Nout][P]
+//   EPI = 0: store the raw products Z.
+//   EPI = 1/2: fused one-electron-layer epilogue (network.py:524-528): z = Z + S + b, tanh chain rule on
+//              the jets, (EPI = 2) residual with the layer input rows, store into the next layer's G.
+//              S : [walker][Nout][P] shared spin-mean term, Gout : [walker][tile][ldo rows][P].
+template <typename T, int NB, int ST, int EPI>
+__global__ void __launch_bounds__(1024 / NB, (NB == 4 ? 2 : 1))
+k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride, const T* __restrict__ W, int K,
+           const T* __restrict__ X2, size_t x2_walker_stride, const T* __restrict__ W2, int K2, int n_tiles,
+           T* __restrict__ Z, size_t z_walker_stride, int Nout, int P, const T* __restrict__ Sb,
+           const T* __restrict__ bias) {
+    typedef typename Acc4<T>::type acc_t;
+    const int tile = blockIdx.x, w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4, n0 = wave * 16 * NB;
+    const T* Xp;
+    const T* Wp;
+    int nks;
+    if (tile < n_tiles) {
+        Xp = X + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride;
+        Wp = W;
+        nks = K / 4;
+    } else {
+        Xp = X2 + (size_t)w * x2_walker_stride;
+        Wp = W2;
+        nks = K2 / 4;
+    }
+    Xp += (size_t)lq * P + lr;
+    Wp += (size_t)lq * Nout + n0 + lr;
+    acc_t acc[NB][ST];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int s = 0; s < ST; ++s) acc[a][s] = acc_t{0, 0, 0, 0};
+    T a0[NB], b0[ST], a1[NB], b1[ST];
+#pragma unroll
+    for (int a = 0; a < NB; ++a) a0[a] = Wp[16 * a];
+#pragma unroll
+    for (int s = 0; s < ST; ++s) b0[s] = Xp[16 * s];
+    {
+        const int k1 = nks > 1 ? 1 : 0;
+#pragma unroll
+        for (int a = 0; a < NB; ++a) a1[a] = Wp[(size_t)4 * k1 * Nout + 16 * a];
+#pragma unroll
+        for (int s = 0; s < ST; ++s) b1[s] = Xp[(size_t)4 * k1 * P + 16 * s];
+    }
+    for (int ks = 0; ks < nks; ks += 2) {
+        // operands two k-steps ahead are requested before the current MFMAs are issued
+        T a2[NB], b2[ST], a3[NB], b3[ST];
+        const int k2 = ks + 2 < nks ? ks + 2 : nks - 1, k3 = ks + 3 < nks ? ks + 3 : nks - 1;
+#pragma unroll
+        for (int a = 0; a < NB; ++a) a2[a] = Wp[(size_t)4 * k2 * Nout + 16 * a];
+#pragma unroll
+        for (int s = 0; s < ST; ++s) b2[s] = Xp[(size_t)4 * k2 * P + 16 * s];
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(a0[a], b0[s], acc[a][s]);
+#pragma unroll
+        for (int a = 0; a < NB; ++a) a3[a] = Wp[(size_t)4 * k3 * Nout + 16 * a];
+#pragma unroll
+        for (int s = 0; s < ST; ++s) b3[s] = Xp[(size_t)4 * k3 * P + 16 * s];
+        if (ks + 1 < nks) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(a1[a], b1[s], acc[a][s]);
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a) { a0[a] = a2[a]; a1[a] = a3[a]; }
+#pragma unroll
+        for (int s = 0; s < ST; ++s) { b0[s] = b2[s]; b1[s] = b3[s]; }
+    }
+    if (EPI == 0) {
+        T* Zp = Z + (size_t)w * z_walker_stride + (size_t)tile * Nout * P;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * a + acc_row<T>(lane, r);
+#pragma unroll
+                for (int s = 0; s < ST; ++s) Zp[(size_t)n * P + 16 * s + lr] = acc[a][s][r];
+            }
+    } else {
+        // Z here is the next layer's G: [walker][tile][x_tile_stride / P rows][P] (same geometry as X)
+        const T rs2 = T(0.70710678118654752440);
+        const T* Sp = Sb + (size_t)w * Nout * P + lr;
+        const T* Gi = X + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
+        T* Go = Z + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
+        const int base = lane & 48;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * a + acc_row<T>(lane, r);
+                T z[ST], hv[ST];
+                T ss = 0;
+#pragma unroll
+                for (int s = 0; s < ST; ++s) z[s] = Sp[(size_t)n * P + 16 * s];
+                if (EPI == 2) {
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) hv[s] = Gi[(size_t)n * P + 16 * s];
+                }
+                const T bn = bias[n];
+#pragma unroll
+                for (int s = 0; s < ST; ++s) {
+                    z[s] += acc[a][s][r];
+                    if (16 * s + lr >= 2) ss += z[s] * z[s];
+                }
+                if (lr == 0) z[0] += bn;
+                ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+                const T z0 = __shfl(z[0], base), zL = __shfl(z[0], base | 1);
+                const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
+#pragma unroll
+                for (int s = 0; s < ST; ++s) {
+                    T o = d1 * z[s];
+                    if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
+                    if (EPI == 2) o = (hv[s] + o) * rs2;
+                    Go[(size_t)n * P + 16 * s] = o;
+                }
+            }
+    }
+}
+
+// spin means of the new one-electron stream:  MEAN[w][sp][n][slot] = mean_{i in sp} G[w][i][n][slot]
+template <typename T>
+__global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restrict__ G, T* __restrict__ MEANout, int Nout) {
+    const int w = blockIdx.z, sp = blockIdx.y, P = S.P;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)Nout * P) return;
+    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn;
+    const T* g = G + ((size_t)(w * S.N + i0) * S.ldk) * P + e;
+    T acc = 0;
+#pragma unroll 4
+    for (int i = 0; i < ns; ++i) acc += g[(size_t)i * S.ldk * P];
+    MEANout[(((size_t)w * S.nch + sp) * Nout) * P + e] = acc / T(ns);
+}
+
+// tanh chain rule on the jets + residual + spin means (network.py:521-533).
+//   Z : [walker][N+1][Nout][P]  (tile N = shared term S);   Gin/Gout : [walker][N][ldk][P]
+//   16 lanes own one feature row (its P slots, ST per lane); a block of 256 threads owns 16 rows
+//   of one walker and walks the electrons, so the means are accumulated in registers.
+template <typename T, int ST, bool RES>
+__global__ void __launch_bounds__(256) k_layer_epilogue(SysDev<T> S, const T* __restrict__ Z, const T* __restrict__ bias,
+                                                        const T* __restrict__ Gin, T* __restrict__ Gout,
+                                                        T* __restrict__ MEANout, int Nout) {
+    const int w = blockIdx.y, tid = threadIdx.x, lr = tid & 15, n = blockIdx.x * 16 + (tid >> 4);
+    const int N = S.N, P = S.P, lane = tid & 63, base = lane & 48;
+    const T rs2 = T(0.70710678118654752440);
+    const T* Zw = Z + (size_t)w * (N + 1) * Nout * P + (size_t)n * P + lr;
+    T sv[ST], macc[ST];
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+        sv[s] = Zw[(size_t)N * Nout * P + 16 * s];
+        macc[s] = 0;
+    }
+    if (lr == 0) sv[0] += bias[n];
+    for (int i = 0; i < N; ++i) {
+        T z[ST];
+        T ss = 0;
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            z[s] = Zw[(size_t)i * Nout * P + 16 * s] + sv[s];
+            if (16 * s + lr >= 2) ss += z[s] * z[s];
+        }
+        ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+        const T z0 = __shfl(z[0], base), zL = __shfl(z[0], base | 1);
+        const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
+        const size_t go = ((size_t)(w * N + i) * S.ldk + n) * P + lr;
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            T o = d1 * z[s];
+            if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
+            if (RES) o = (Gin[go + 16 * s] + o) * rs2;
+            Gout[go + 16 * s] = o;
+            macc[s] += o;
+        }
+        const bool last_up = (i == S.n_up - 1), last = (i == N - 1);
+        if (last_up || last) {
+            const int sp = last_up ? 0 : 1;
+            const T inv_ns = T(1) / T(sp == 0 ? S.n_up : S.n_dn);
+            T* Mo = MEANout + (((size_t)w * S.nch + sp) * Nout + n) * P + lr;
+#pragma unroll
+            for (int s = 0; s < ST; ++s) { Mo[16 * s] = macc[s] * inv_ns; macc[s] = 0; }
+        }
+    }
+}
+
+// Orbital head epilogue (network.py:543-557): complex phi = (Phi[p], Phi[nparam + p]),
+// M = phi * q with q = envelope * Bloch phase (a 5-jet in the electron's own coordinates).
+//   Phi  : [walker][electron in spin][ocols][P]  (the GEMM output, natural column order)
+//   MOUT : [walker][spin][det][elec][orb][re/im][P]
+template <typename T, int ST>
+__global__ void __launch_bounds__(256) k_orbital_epilogue(SysDev<T> S, const T* __restrict__ PHI, size_t phi_walker_stride,
+                                                          const T* __restrict__ Q, T* __restrict__ MOUT, int sp,
+                                                          size_t mout_stride, size_t mout_off) {
+    const int ii = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, lr = tid & 15, g = tid >> 4;
+    const int lane = tid & 63, base = lane & 48;
+    const int N = S.N, P = S.P, OC = S.ocols[sp];
+    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn, nparam = S.nparam[sp];
+    const int i = i0 + ii, so = 2 + 3 * i;
+    const T* Pw = PHI + (size_t)w * phi_walker_stride + (size_t)ii * OC * P + lr;
+    T* Mw = MOUT + (size_t)w * mout_stride + mout_off;
+    for (int p0 = 0; p0 < nparam; p0 += 16) {
+        const int p = p0 + g;
+        const bool valid = p < nparam;
+        const int pc = valid ? p : 0;
+        const T* q = Q + ((size_t)(w * N + i) * S.nparam_max + pc) * 10;
+        const Cx<T> qv(q[0], q[1]), qg0(q[2], q[3]), qg1(q[4], q[5]), qg2(q[6], q[7]), ql(q[8], q[9]);
+        Cx<T> phi[ST];
+#pragma unroll
+        for (int s = 0; s < ST; ++s)
+            phi[s] = Cx<T>(Pw[(size_t)pc * P + 16 * s], Pw[(size_t)(nparam + pc) * P + 16 * s]);
+        const Cx<T> f0(__shfl(phi[0].re, base), __shfl(phi[0].im, base));
+        const Cx<T> fL(__shfl(phi[0].re, base | 1), __shfl(phi[0].im, base | 1));
+        Cx<T> fo[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int sl = so + c, st = sl >> 4, src = base | (sl & 15);
+            T re = 0, im = 0;
+#pragma unroll
+            for (int s = 0; s < ST; ++s) {
+                const T tr = __shfl(phi[s].re, src), ti = __shfl(phi[s].im, src);
+                if (s == st) { re = tr; im = ti; }
+            }
+            fo[c] = Cx<T>(re, im);
+        }
+        const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
+        if (!valid) continue;
+        const int kdet = p / ns, m = p % ns;
+        T* mo = Mw + (((size_t)(kdet * ns + ii) * ns + m) * 2) * P + lr;
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            const int slot = 16 * s + lr;
+            Cx<T> v = phi[s] * qv;
+            if (slot == 1) v = lap;
+            else if (slot == so) v = v + f0 * qg0;
+            else if (slot == so + 1) v = v + f0 * qg1;
+            else if (slot == so + 2) v = v + f0 * qg2;
+            mo[16 * s] = v.re;
+            mo[P + 16 * s] = v.im;
+        }
+    }
+}
+
+}  // namespace ds

@@ -4,7 +4,7 @@
 //   jet tensors carry, for every scalar, P = roundup16(3N+2) "slots" contiguous in memory:
 //       slot 0 value | slot 1 Laplacian | slot 2+3j+c = d/dx_{j,c} | zero padding
 //   G    [walker][electron i][row k][P]   rows 0..h1-1 : one-electron stream h_i
-//                                         rows h1..    : mean_j h2_ij over spin-up j, then spin-down j
+//                                         rows h1..    : mean_j h2_ji over spin-up j, then spin-down j
 //   MEAN [walker][spin][k][P]             spin means of h (the shared part of the layer input)
 //   H2   [walker][k2][5][NP]              two-electron stream, 5 = (value, d/dr_x, d/dr_y, d/dr_z, Laplacian)
 //                                         as a function of r = x_i - x_j; NP = roundup16(N*N), pair = i*N+j
@@ -239,178 +239,7 @@ __global__ void __launch_bounds__(256) k_two_layer(SysDev<T> S, const T* __restr
         }
 }
 
-// =====================================================================================
-// 3. one-electron stream layer  (network.py:521-533)
-//      z_i = W_loc^T [h_i ; m2_i] + ( W_sh^T [mean_up h ; mean_dn h] + b ),   h_i <- res(h_i, tanh z_i)
-//    One wave owns 64 output features of one walker and walks the electrons; the shared term S is
-//    computed once per walker (prologue) and parked in HBM scratch private to this wave.
-//    A wave owns 16*NB output features x all ST = P/16 slot tiles.  Grid (B), block 64 * Nout/(16 NB).
-// =====================================================================================
-template <typename T, int NB, int ST, bool RES>
-__global__ void __launch_bounds__(1024 / NB) k_single_layer(SysDev<T> S, const T* __restrict__ Gin, T* __restrict__ Gout,
-                                                      const T* __restrict__ Wloc, const T* __restrict__ Wsh,
-                                                      const T* __restrict__ bias, const T* __restrict__ MEANin,
-                                                      T* __restrict__ MEANout, T* __restrict__ SB, int Kloc, int Ksh,
-                                                      int Nout) {
-    typedef typename Acc4<T>::type acc_t;
-    const int w = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lr = lane & 15, lq = lane >> 4, n0 = wave * 16 * NB;
-    const int N = S.N, P = S.P;
-    acc_t acc[NB][ST];
-    // ---- prologue: shared term
-    for (int a = 0; a < NB; ++a)
-        for (int s = 0; s < ST; ++s) acc[a][s] = acc_t{0, 0, 0, 0};
-    {
-        const T* Mw = MEANin + (size_t)w * Ksh * P + lr;
-        const T* Wp = Wsh + n0 + lr;
-        for (int ks = 0; ks < Ksh / 4; ++ks) {
-            T av[NB], bv[ST];
-            for (int a = 0; a < NB; ++a) av[a] = Wp[(size_t)(4 * ks + lq) * Nout + 16 * a];
-            for (int s = 0; s < ST; ++s) bv[s] = Mw[(size_t)(4 * ks + lq) * P + 16 * s];
-            for (int a = 0; a < NB; ++a)
-                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[a], bv[s], acc[a][s]);
-        }
-    }
-    T* Sw = SB + (size_t)w * Nout * P;
-    for (int a = 0; a < NB; ++a)
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + 16 * a + acc_row<T>(lane, r);
-            for (int s = 0; s < ST; ++s) {
-                T v = acc[a][s][r];
-                if (s == 0 && lr == 0) v += bias[n];
-                Sw[(size_t)n * P + 16 * s + lr] = v;
-            }
-        }
-    // ---- electrons
-    const T rs2 = T(0.70710678118654752440);
-    const T* Wp = Wloc + n0 + lr;
-    for (int i = 0; i < N; ++i) {
-        const T* Gi = Gin + (size_t)(w * N + i) * S.ldk * P;
-        const T* Gp = Gi + lr;
-        for (int a = 0; a < NB; ++a)
-            for (int s = 0; s < ST; ++s) acc[a][s] = acc_t{0, 0, 0, 0};
-        T av[NB], bv[ST];
-        for (int a = 0; a < NB; ++a) av[a] = Wp[(size_t)lq * Nout + 16 * a];
-        for (int s = 0; s < ST; ++s) bv[s] = Gp[(size_t)lq * P + 16 * s];
-        const int nks = Kloc / 4;
-        for (int ks = 0; ks < nks; ++ks) {
-            T an[NB], bn[ST];
-            const int kn = (ks + 1 < nks) ? ks + 1 : ks;       // prefetch next k-step
-            for (int a = 0; a < NB; ++a) an[a] = Wp[(size_t)(4 * kn + lq) * Nout + 16 * a];
-            for (int s = 0; s < ST; ++s) bn[s] = Gp[(size_t)(4 * kn + lq) * P + 16 * s];
-            for (int a = 0; a < NB; ++a)
-                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[a], bv[s], acc[a][s]);
-            for (int a = 0; a < NB; ++a) av[a] = an[a];
-            for (int s = 0; s < ST; ++s) bv[s] = bn[s];
-        }
-        // ---- epilogue: tanh chain rule on the jets, residual, spin-mean accumulation
-        const int sp = spin_of(i, S.n_up);
-        const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn;
-        const T inv_ns = T(1) / T(ns);
-        T* Go = Gout + (size_t)(w * N + i) * S.ldk * P;
-        T* Mo = MEANout + ((size_t)w * S.nch + sp) * Nout * P;
-        for (int a = 0; a < NB; ++a)
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + 16 * a + acc_row<T>(lane, r);
-                T z[ST];
-                T ss = 0;
-                for (int s = 0; s < ST; ++s) {
-                    z[s] = acc[a][s][r] + Sw[(size_t)n * P + 16 * s + lr];
-                    const int slot = 16 * s + lr;
-                    if (slot >= 2) ss += z[s] * z[s];
-                }
-                ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
-                const T z0 = __shfl(z[0], lane & 48), zL = __shfl(z[0], (lane & 48) | 1);
-                const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
-                for (int s = 0; s < ST; ++s) {
-                    const int slot = 16 * s + lr;
-                    T o = d1 * z[s];
-                    if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
-                    if (RES) o = (Gi[(size_t)n * P + slot] + o) * rs2;
-                    Go[(size_t)n * P + slot] = o;
-                    T* mp = Mo + (size_t)n * P + slot;
-                    *mp = (i == i0) ? o * inv_ns : *mp + o * inv_ns;
-                }
-            }
-    }
-}
-
-// =====================================================================================
-// 4. orbital head (network.py:539-557): phi = h W_orb (complex), M = phi * q, product rule on jets.
-//    Packed weight columns put Re/Im of the same orbital in the same lane (see pack_params).
-//    Grid (ocols/(16 NB), B), block 64; loops over the electrons of spin `sp`.
-// =====================================================================================
-template <typename T, int NB, int ST>
-__global__ void __launch_bounds__(64) k_orbital(SysDev<T> S, const T* __restrict__ Gin, const T* __restrict__ Worb,
-                                                const T* __restrict__ Q, T* __restrict__ MOUT, int sp, size_t mout_stride,
-                                                size_t mout_off) {
-    typedef typename Acc4<T>::type acc_t;
-    const int cb = blockIdx.x, w = blockIdx.y, lane = threadIdx.x & 63;
-    const int lr = lane & 15, lq = lane >> 4, n0 = cb * 16 * NB;
-    const int N = S.N, P = S.P, Kh = S.h1[S.n_layers], OC = S.ocols[sp];
-    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn, nparam = S.nparam[sp];
-    const T* Wp = Worb + n0 + lr;
-    T* Mw = MOUT + (size_t)w * mout_stride + mout_off;
-    for (int ii = 0; ii < ns; ++ii) {
-        const int i = i0 + ii;
-        const T* Gp = Gin + (size_t)(w * N + i) * S.ldk * P + lr;
-        acc_t acc[NB][ST];
-        for (int a = 0; a < NB; ++a)
-            for (int s = 0; s < ST; ++s) acc[a][s] = acc_t{0, 0, 0, 0};
-        T av[NB], bv[ST];
-        for (int a = 0; a < NB; ++a) av[a] = Wp[(size_t)lq * OC + 16 * a];
-        for (int s = 0; s < ST; ++s) bv[s] = Gp[(size_t)lq * P + 16 * s];
-        const int nks = Kh / 4;
-        for (int ks = 0; ks < nks; ++ks) {
-            T an[NB], bn[ST];
-            const int kn = (ks + 1 < nks) ? ks + 1 : ks;
-            for (int a = 0; a < NB; ++a) an[a] = Wp[(size_t)(4 * kn + lq) * OC + 16 * a];
-            for (int s = 0; s < ST; ++s) bn[s] = Gp[(size_t)(4 * kn + lq) * P + 16 * s];
-            for (int a = 0; a < NB; ++a)
-                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[a], bv[s], acc[a][s]);
-            for (int a = 0; a < NB; ++a) av[a] = an[a];
-            for (int s = 0; s < ST; ++s) bv[s] = bn[s];
-        }
-        // own-direction slots of electron i: slot 2+3i+c
-        const int so = 2 + 3 * i;
-        for (int a = 0; a < NB; ++a)
-            for (int ab = 0; ab < 2; ++ab) {
-                // register pair (2ab, 2ab+1) = (Re, Im) of orbital p  [packing: see header comment]
-                const int p = 8 * (NB * cb + a) + (lane >> 4) + 4 * ab;
-                const bool valid = p < nparam;
-                const T* q = Q + ((size_t)(w * N + i) * S.nparam_max + (valid ? p : 0)) * 10;
-                Cx<T> qv(q[0], q[1]), qg[3] = {Cx<T>(q[2], q[3]), Cx<T>(q[4], q[5]), Cx<T>(q[6], q[7])}, ql(q[8], q[9]);
-                Cx<T> phi[ST];
-                for (int s = 0; s < ST; ++s) phi[s] = Cx<T>(acc[a][s][2 * ab], acc[a][s][2 * ab + 1]);
-                const int base = lane & 48;
-                Cx<T> p0(__shfl(phi[0].re, base), __shfl(phi[0].im, base));
-                Cx<T> pL(__shfl(phi[0].re, base | 1), __shfl(phi[0].im, base | 1));
-                Cx<T> pown[3];
-                for (int c = 0; c < 3; ++c) {
-                    const int sl = so + c, st = sl >> 4, src = base | (sl & 15);
-                    T re = 0, im = 0;
-                    for (int s = 0; s < ST; ++s) {
-                        const T tr = __shfl(phi[s].re, src), ti = __shfl(phi[s].im, src);
-                        if (s == st) { re = tr; im = ti; }
-                    }
-                    pown[c] = Cx<T>(re, im);
-                }
-                Cx<T> lap = pL * qv + p0 * ql;
-                for (int c = 0; c < 3; ++c) lap = lap + T(2) * (pown[c] * qg[c]);
-                if (!valid) continue;
-                const int kdet = p / ns, m = p % ns;
-                T* mo = Mw + (((size_t)(kdet * ns + ii) * ns + m) * 2) * P;
-                for (int s = 0; s < ST; ++s) {
-                    const int slot = 16 * s + lr;
-                    Cx<T> v = phi[s] * qv;
-                    if (slot == 1) v = lap;
-                    else if (slot >= so && slot < so + 3) v = v + p0 * qg[slot - so];
-                    mo[slot] = v.re;
-                    mo[P + slot] = v.im;
-                }
-            }
-    }
-}
+// (3. one-electron stream layer and 4. orbital head: ds_gemm.h)
 
 // =====================================================================================
 // 5a. inverse + log det of every (walker, spin, det) value matrix: Gauss-Jordan, partial pivoting,

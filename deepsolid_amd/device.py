@@ -229,21 +229,10 @@ class DeviceSystem:
         return flat
 
     def _orbital_column_map(self, nparam, cols):
-        """Packed column c -> reference column of orbital[s]['w'] (or -1 for padding).
-        Within every 16-column tile the MFMA accumulator gives one lane the rows
-        {q, q+4, q+8, q+12} (f64) or {4q..4q+3} (f32); they are assigned
-        (Re p, Im p, Re p+4, Im p+4) with p = 8*tile + q, so the complex product with the
-        envelope/phase jet is lane-local (kernel k_orbital)."""
+        """Packed column c -> reference column of orbital[s]['w'] (or -1 for the zero padding that
+        rounds 2*nparam up to a multiple of 64): natural order, Re columns then Im columns."""
         src = -np.ones(cols, dtype=np.int64)
-        for c in range(cols):
-            t, o = divmod(c, 16)
-            if self.dtype == torch.float64:
-                q, r = o % 4, o // 4
-            else:
-                q, r = o // 4, o % 4
-            p = 8 * t + q + 4 * (r // 2)
-            if p < nparam:
-                src[c] = p + (r % 2) * nparam
+        src[:2 * nparam] = np.arange(2 * nparam)
         return src
 
     # ------------------------------------------------------------------ calls
