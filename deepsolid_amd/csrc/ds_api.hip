@@ -283,7 +283,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
         {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
-            hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc), dim3(256), (size_t)S.nch * K2 * 5 * sizeof(T), st, S,
+            hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) * sizeof(T), st, S,
                                c.H2[hi], K2, c.G[gi], Kh);
         }
         if (stop == STOP_G0 + l) return copy_out(dr, c.G[gi], L.G * Bc, st);
@@ -661,10 +661,18 @@ int ds_profile_read(ds_system* s, double* ms_total, int64_t* launches) {
     return 0;
 }
 
-int64_t ds_mfma_f64_peak(int64_t iters, void* scratch, void* stream) {
-    const int blocks = 256 * 2;   // two 4-wave blocks per CU
-    hipLaunchKernelGGL(ds::k_mfma_peak, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)iters, (double*)scratch);
-    return (int64_t)blocks * 4 * iters * 8 * 2048;   // waves * iters * mfma per iter * flop per mfma
+int64_t ds_mfma_f64_peak(int64_t iters, int blocks_per_cu, int n_acc, void* scratch, void* stream) {
+    const int blocks = 256 * blocks_per_cu;   // 4-wave blocks: blocks_per_cu waves per SIMD
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_acc) {
+        case 1: hipLaunchKernelGGL(ds::k_mfma_peak<1>, dim3(blocks), dim3(256), 0, st, (long)iters, (double*)scratch); break;
+        case 2: hipLaunchKernelGGL(ds::k_mfma_peak<2>, dim3(blocks), dim3(256), 0, st, (long)iters, (double*)scratch); break;
+        case 4: hipLaunchKernelGGL(ds::k_mfma_peak<4>, dim3(blocks), dim3(256), 0, st, (long)iters, (double*)scratch); break;
+        case 8: hipLaunchKernelGGL(ds::k_mfma_peak<8>, dim3(blocks), dim3(256), 0, st, (long)iters, (double*)scratch); break;
+        case 16: hipLaunchKernelGGL(ds::k_mfma_peak<16>, dim3(blocks), dim3(256), 0, st, (long)iters, (double*)scratch); break;
+        default: fail("n_acc must be 1, 2, 4, 8 or 16"); return -1;
+    }
+    return (int64_t)blocks * 4 * iters * n_acc * 2048;   // waves * iters * mfma per iter * flop per mfma
 }
 
 }  // extern "C"

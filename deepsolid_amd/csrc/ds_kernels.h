@@ -7,7 +7,8 @@
 //                                         rows h1..    : mean_j h2_ji over spin-up j, then spin-down j
 //   MEAN [walker][spin][k][P]             spin means of h (the shared part of the layer input)
 //   H2   [walker][k2][5][NP]              two-electron stream, 5 = (value, d/dr_x, d/dr_y, d/dr_z, Laplacian)
-//                                         as a function of r = x_i - x_j; NP = roundup16(N*N), pair = i*N+j
+//                                         h2[j][e] as a function of r = x_j - x_e, stored at pair = e*N + j;
+//                                         NP = roundup16(N*N)
 //   MOUT [walker][spin][det k][elec i][orb m][re/im][P]   orbital matrices with all slots
 //
 // Every dense contraction is computed TRANSPOSED, C[n][slot] = sum_k W[k][n] * X[k][slot], so that
@@ -106,12 +107,14 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
     // two-electron stream (pair features of r = x_i - x_j in the simulation cell; diagonal masked,
     // network.py:294-300)
     T* Hw = H2 + (size_t)w * S.h2[0] * 5 * NP;   // caller passes stride for 4 rows via h2[0]
+    // stored pair index q = e*N + j holds h2[j][e] (first electron j, second electron e), r = x_j - x_e:
+    // network.py:323-328 averages over the FIRST index, so electron e's partners are contiguous.
     for (int pr = tid; pr < NP; pr += nt) {
-        const int i = pr / N, j = pr % N;
+        const int e = pr / N, j = pr % N;
         Jet5<T> o[4];
-        if (pr < N * N && i != j) {
+        if (pr < N * N && e != j) {
             T r[3];
-            for (int c = 0; c < 3; ++c) r[c] = sx[3 * i + c] - sx[3 * j + c];
+            for (int c = 0; c < 3; ++c) r[c] = sx[3 * j + c] - sx[3 * e + c];
             nu_distance_jet(r, S.sim_AV, S.sim_BV, S.L, o);
         } else {
             for (int f = 0; f < 4; ++f) o[f] = jet_zero<T>();
@@ -121,7 +124,7 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
             Hw[(size_t)(f * 5 + 1) * NP + pr] = o[f].g[0];
             Hw[(size_t)(f * 5 + 2) * NP + pr] = o[f].g[1];
             Hw[(size_t)(f * 5 + 3) * NP + pr] = o[f].g[2];
-            Hw[(size_t)(f * 5 + 4) * NP + pr] = 2 * o[f].l;    // Laplacian over x_i AND x_j
+            Hw[(size_t)(f * 5 + 4) * NP + pr] = 2 * o[f].l;    // Laplacian over x_j AND x_e
         }
     }
     // q_i[p] = envelope_i[p] * exp(i k_m . x_i), p = det*n_s + m, as a complex 5-jet in x_i
@@ -167,22 +170,23 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
 template <typename T>
 __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restrict__ H2, int K2, T* __restrict__ G, int row0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* sums = reinterpret_cast<T*>(smem_raw);   // [nch][K2][5]
-    const int i = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    const int e = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int N = S.N, P = S.P, NP = S.NP;
-    const T* Hw = H2 + (size_t)w * K2 * 5 * NP;
-    // network.py:323,328: h_two is split and averaged along its FIRST electron axis, so the feature
-    // of electron i is mean_{j in spin} h2[j][i], a function of r = x_j - x_i (d/dx_j = +d/dr, d/dx_i = -d/dr)
+    T* hs = reinterpret_cast<T*>(smem_raw);     // [K2*5][N]  pair jets h2[j][e], j = 0..N-1
+    T* sums = hs + K2 * 5 * N;                  // [nch][K2][5]
+    const T* Hw = H2 + (size_t)w * K2 * 5 * NP + (size_t)e * N;
+    for (int idx = tid; idx < K2 * 5 * N; idx += nt) hs[idx] = Hw[(size_t)(idx / N) * NP + idx % N];
+    __syncthreads();
     for (int idx = tid; idx < S.nch * K2 * 5; idx += nt) {
-        const int c = idx % 5, k = (idx / 5) % K2, s = idx / (5 * K2);
+        const int kc = idx % (5 * K2), s = idx / (5 * K2);
         const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
-        const T* hp = Hw + (size_t)(k * 5 + c) * NP + i;
         T v = 0;
-        for (int j = j0; j < j0 + ns; ++j) v += hp[j * N];
+        for (int j = j0; j < j0 + ns; ++j) v += hs[kc * N + j];
         sums[idx] = v / T(ns);
     }
     __syncthreads();
-    T* Gi = G + ((size_t)(w * N + i) * S.ldk + row0) * P;
+    // h2[j][e] depends on r = x_j - x_e: d/dx_j = +d/dr, d/dx_e = -d/dr
+    T* Ge = G + ((size_t)(w * N + e) * S.ldk + row0) * P;
     for (int idx = tid; idx < S.nch * K2 * P; idx += nt) {
         const int slot = idx % P, k = (idx / P) % K2, s = idx / (P * K2);
         const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
@@ -191,10 +195,10 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
         else if (slot == 1) v = sums[(s * K2 + k) * 5 + 4];
         else if (slot < S.D) {
             const int j = (slot - 2) / 3, c = (slot - 2) % 3;
-            if (j == i) v = -sums[(s * K2 + k) * 5 + 1 + c];
-            else if (j >= j0 && j < j0 + ns) v = Hw[(size_t)(k * 5 + 1 + c) * NP + j * N + i] / T(ns);
+            if (j == e) v = -sums[(s * K2 + k) * 5 + 1 + c];
+            else if (j >= j0 && j < j0 + ns) v = hs[(k * 5 + 1 + c) * N + j] / T(ns);
         }
-        Gi[idx] = v;
+        Ge[idx] = v;
     }
 }
 
@@ -594,18 +598,19 @@ __global__ void k_gather_slot0(const T* __restrict__ MOUT, size_t mout_stride, s
     if (idx < per) out[w * per + idx] = MOUT[w * mout_stride + mout_off + idx * P];
 }
 
-// fp64 MFMA issue-rate probe
+// fp64 MFMA issue-rate probe: NACC independent accumulators per wave
+template <int NACC>
 __global__ void __launch_bounds__(256) k_mfma_peak(long iters, double* out) {
     typedef Acc4<double>::type acc_t;
-    acc_t acc[8];
-    for (int j = 0; j < 8; ++j) acc[j] = acc_t{0, 0, 0, 0};
+    acc_t acc[NACC];
+    for (int j = 0; j < NACC; ++j) acc[j] = acc_t{0, 0, 0, 0};
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
     for (long it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = mfma16(a, b, acc[j]);
+        for (int j = 0; j < NACC; ++j) acc[j] = mfma16(a, b, acc[j]);
     }
     double s = 0;
-    for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
     if (s == 12345.678) out[0] = s;   // keep the chain alive
 }
 

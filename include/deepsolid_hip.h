@@ -176,10 +176,10 @@ int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_
 int ds_profile_enable(ds_system* sys, int on);
 int ds_profile_read(ds_system* sys, double* ms_total, int64_t* launches);
 
-/* fp64 MFMA issue-rate micro-benchmark used by bench.py to confirm the roofline peak:
- * runs `iters` dependent-free v_mfma_f64_16x16x4_f64 per wave on every SIMD, returns
- * FLOPs executed; the caller times it with HIP events. */
-int64_t ds_mfma_f64_peak(int64_t iters, void* scratch, void* stream);
+/* fp64 MFMA issue-rate micro-benchmark used to confirm the roofline peak: every wave issues
+ * `iters` x `n_acc` independent v_mfma_f64_16x16x4_f64 (n_acc = 1,2,4,8,16 accumulators), with
+ * `blocks_per_cu` waves resident per SIMD; returns the FLOPs executed (caller times with HIP events). */
+int64_t ds_mfma_f64_peak(int64_t iters, int blocks_per_cu, int n_acc, void* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -96,14 +96,14 @@ def test_stages_vs_forward_laplacian_oracle(name):
         """(k2,5,NP) pair jets -> dense (N,N,k2,D) like the oracle."""
         k2 = h.shape[0]
         out = np.zeros((N, N, k2, D))
-        hp = h[:, :, :N * N].reshape(k2, 5, N, N)
-        out[..., 0] = hp[:, 0].transpose(1, 2, 0)
-        out[..., 1] = hp[:, 4].transpose(1, 2, 0)
+        hp = h[:, :, :N * N].reshape(k2, 5, N, N)          # [k][c][second e][first j]
+        out[..., 0] = hp[:, 0].transpose(2, 1, 0)          # out[first][second]
+        out[..., 1] = hp[:, 4].transpose(2, 1, 0)
         for i in range(N):
             for j in range(N):
                 if i != j:
-                    out[i, j, :, 2 + 3 * i:5 + 3 * i] = hp[:, 1:4, i, j]
-                    out[i, j, :, 2 + 3 * j:5 + 3 * j] = -hp[:, 1:4, i, j]
+                    out[i, j, :, 2 + 3 * i:5 + 3 * i] = hp[:, 1:4, j, i]
+                    out[i, j, :, 2 + 3 * j:5 + 3 * j] = -hp[:, 1:4, j, i]
         return out
 
     for l in range(nl + 1):
