@@ -12,7 +12,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from . import distance as _distance
 
 _DTYPES = {torch.float64: 0, torch.float32: 1}
 
@@ -239,6 +238,8 @@ class DeviceSystem:
     def ewald(self, x):
         x = self._check_x(x)
         out = torch.empty(x.shape[0], 3, dtype=self.dtype, device=self.device)
+        if x.shape[0] == 0:
+            return out
         _lib.check(self.lib.ds_ewald(self.handle, _ptr(x), x.shape[0], _ptr(out), _stream()), 'ds_ewald')
         return out
 
@@ -251,6 +252,8 @@ class DeviceSystem:
         ew = torch.empty(B, dtype=self.dtype, device=self.device)
         la = torch.empty(B, dtype=self.dtype, device=self.device) if want_logpsi else None
         ph = torch.empty(B, 2, dtype=self.dtype, device=self.device) if want_logpsi else None
+        if B == 0:
+            return ke, ew, la, ph
         _lib.check(self.lib.ds_local_energy(self.handle, _ptr(p), _ptr(x), B, _ptr(ke), _ptr(ew), _ptr(la), _ptr(ph),
                                             _ptr(ws), ws.numel(), _stream()), 'ds_local_energy')
         return ke, ew, la, ph
@@ -262,6 +265,8 @@ class DeviceSystem:
         ws = self.workspace(B, ws_bytes)
         la = torch.empty(B, dtype=self.dtype, device=self.device)
         ph = torch.empty(B, 2, dtype=self.dtype, device=self.device)
+        if B == 0:
+            return la, ph
         _lib.check(self.lib.ds_logpsi(self.handle, _ptr(p), _ptr(x), B, _ptr(la), _ptr(ph), _ptr(ws), ws.numel(),
                                       _stream()), 'ds_logpsi')
         return la, ph

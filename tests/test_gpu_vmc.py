@@ -1,0 +1,127 @@
+"""GPU tests of the callers around the kernel chain: Metropolis update (qmc.py), total_energy
+primal (train.py), wavefunction properties of the reference's test/test_network.py at the full
+BASELINE batch, determinism and ragged / empty batches."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import network as onet
+from oracle import train as otrain
+
+from common import load_case, oracle_net, tt
+from test_gpu_parity import dev_params
+
+pytestmark = pytest.mark.gpu
+
+
+def nets(cell, klist, net_kw, *methods):
+    from deepsolid_amd import network
+    return [network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name=m, **net_kw) for m in methods]
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'bcc_li'])
+def test_metropolis_vs_reference_vectors(name):
+    """mh_update and a 3-step mcmc_step replaying the noise the reference consumed."""
+    from deepsolid_amd import qmc
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    (slog,) = nets(cell, klist, net_kw, 'eval_slogdet')
+    cu = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device='cuda')
+    nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    xn, _, lpn, nacc = qmc.mh_update(dp, slog.apply, cu(fx['mh_x1']), None, cu(fx['mh_lp1']), nacc, cell.a,
+                                     stddev=float(fx['mh_width']), normal=cu(fx['mh_normal']), uniform=cu(fx['mh_uniform']))
+    np.testing.assert_allclose(xn.cpu().numpy(), fx['mh_x_new'], atol=1e-10)
+    np.testing.assert_allclose(lpn.cpu().numpy(), fx['mh_lp_new'], atol=1e-8)
+    assert float(nacc.item()) == float(fx['mh_num_accepts'])
+    step = qmc.make_mcmc_step(slog.apply, fx['mcmc_x0'].shape[0], cell.a, steps=int(fx['mcmc_steps']))
+    xo, pmove = step(dp, cu(fx['mcmc_x0']), (cu(fx['mcmc_normals']), cu(fx['mcmc_uniforms'])), float(fx['mcmc_width']))
+    np.testing.assert_allclose(xo.cpu().numpy(), fx['mcmc_x_out'], atol=1e-10)
+    assert abs(float(pmove) - float(fx['mcmc_pmove'])) < 1e-15
+    # generator-driven path: reproducible, stays in the cell, plausible acceptance
+    x1, p1 = step(dp, cu(fx['mcmc_x0']), 7, 0.02)
+    x2, p2 = step(dp, cu(fx['mcmc_x0']), 7, 0.02)
+    assert torch.equal(x1, x2) and float(p1) == float(p2) and 0.0 <= float(p1) <= 1.0
+    frac = (x1.reshape(x1.shape[0], -1, 3) @ torch.linalg.inv(cu(cell.a)))
+    assert frac.min() > -1e-9 and frac.max() < 1 + 1e-9
+    with pytest.raises(ValueError):
+        qmc.make_mcmc_step(slog.apply, 4, cell.a, importance_sampling=lambda *a: 0, one_electron_moves=True)
+    with pytest.raises(NotImplementedError):
+        qmc.mh_update(dp, slog.apply, cu(fx['mh_x1']), None, cu(fx['mh_lp1']), nacc, cell.a, atoms=cu(np.zeros((1, 3))))
+
+
+@pytest.mark.parametrize('name', ['lih', 'bcc_li'])
+def test_total_energy_vs_oracle(name):
+    from deepsolid_amd import train
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    (net,) = nets(cell, klist, net_kw, 'eval_logdet')
+    x = torch.as_tensor(fx['x'], device='cuda')
+    loss, aux = train.make_loss(net.apply, None, cell)(dp, x)
+    o_loss, o_aux = otrain.make_loss(oracle_net(cell, klist, net_kw, 'eval_logdet').apply, cell,
+                                     mode='for' if name == 'lih' else 'hessian')(onet.params_to_torch(params), tt(fx['x']))
+    assert abs(float(loss) - float(o_loss)) < 1e-8
+    assert abs(float(aux.imaginary) - float(o_aux.imaginary)) < 1e-8
+    assert abs(float(aux.variance) - float(o_aux.variance)) < 1e-7 * max(1.0, abs(float(o_aux.variance)))
+    np.testing.assert_allclose(aux.local_energy.cpu().numpy(), o_aux.local_energy.numpy(), atol=1e-8)
+
+
+def test_wavefunction_properties_at_full_batch():
+    """The three checks of reference test/test_network.py:65-122 on bcc-Li at B = 4096, plus the
+    Laplacian's invariances (E_L is unchanged by the same moves) and bitwise determinism."""
+    from deepsolid_amd import hamiltonian, systems
+    fx, cell, klist, net_kw, params = load_case('bcc_li_twist')
+    dp = dev_params(params)
+    ps, ld = nets(cell, klist, net_kw, 'eval_phase_and_slogdet', 'eval_logdet')
+    B, N = 4096, sum(cell.nelec)
+    x = torch.as_tensor(systems.synthetic_walkers(cell, B, seed=99), device='cuda')
+    p1, s1 = ps.apply(dp, x)
+    # periodic BC: all electrons translated by a primitive lattice vector (test_network.py:65-83)
+    trans = torch.as_tensor(cell.original_cell.a[2], device='cuda')
+    kp = sum(np.sum(k, axis=0) for k in klist)
+    p2, s2 = ps.apply(dp, x + trans.repeat(N))
+    assert (s1 - s2).abs().max() < 1e-9
+    assert (p1 * np.exp(1j * np.dot(kp, cell.original_cell.a[2])) - p2).abs().max() < 1e-8
+    # twisted BC: one electron translated by a supercell vector (test_network.py:86-106)
+    shift = torch.zeros(3 * N, dtype=torch.float64, device='cuda')
+    shift[:3] = torch.as_tensor(cell.a[1], device='cuda')
+    p3, s3 = ps.apply(dp, x + shift)
+    tw = np.exp(1j * np.dot(klist[0][0], cell.a[1]))
+    assert (s1 - s3).abs().max() < 1e-9
+    assert (p3 / p1 - tw).abs().max() < 1e-8
+    # antisymmetry: swap electrons 0 and 1 (same spin) (test_network.py:109-122)
+    xs = torch.cat([x[:, 3:6], x[:, :3], x[:, 6:]], dim=1)
+    p4, s4 = ps.apply(dp, xs)
+    assert (s1 - s4).abs().max() < 1e-9
+    assert (p1 + p4).abs().max() < 1e-8
+    el = hamiltonian.local_energy_seperate(ld.apply, cell)
+    k1, e1 = el(dp, x)
+    k2, e2 = el(dp, x)
+    assert torch.equal(torch.view_as_real(k1), torch.view_as_real(k2)) and torch.equal(e1, e2)
+    k4, e4 = el(dp, xs)
+    scale = k1.abs().clamp(min=1.0)
+    assert ((k1 - k4).abs() / scale).max() < 1e-8 and (e1 - e4).abs().max() < 1e-8
+    k5, e5 = el(dp, x + trans.repeat(N))
+    assert ((k1 - k5).abs() / scale).max() < 1e-8 and (e1 - e5).abs().max() < 1e-8
+    assert torch.isfinite(torch.view_as_real(k1)).all()
+
+
+def test_ragged_and_empty_batches():
+    """B = 1, B not a multiple of the workspace chunk, and an empty batch."""
+    from deepsolid_amd import hamiltonian
+    fx, cell, klist, net_kw, params = load_case('lih')
+    dp = dev_params(params)
+    (net,) = nets(cell, klist, net_kw, 'eval_logdet')
+    sysd = net.apply.system
+    x = torch.as_tensor(np.tile(fx['x'], (3, 1))[:17], device='cuda')
+    ke_all, ew_all, _, _ = sysd.local_energy(dp, x)
+    per = int(sysd.lib.ds_workspace_bytes(sysd.handle, 1))
+    ke_c, ew_c, _, _ = sysd.local_energy(dp, x, ws_bytes=5 * per - 256 * 4)       # chunks of 4 walkers: 4+4+4+4+1
+    assert torch.equal(ke_all, ke_c) and torch.equal(ew_all, ew_c)
+    k1, e1 = hamiltonian.local_energy_seperate(net.apply, cell)(dp, x[5])
+    assert torch.equal(torch.view_as_real(k1), ke_all[5]) and torch.equal(e1, ew_all[5])
+    ke0, ew0, _, _ = sysd.local_energy(dp, x[:0])
+    assert ke0.shape == (0, 2) and ew0.shape == (0,)
+    with pytest.raises(ValueError):
+        sysd.local_energy(dp, x[:, :-3])
+    with pytest.raises(RuntimeError):
+        sysd.local_energy(dp, x.cpu())
