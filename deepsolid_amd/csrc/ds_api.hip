@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/deepsolid_hip.h"
-#include "ds_gemm.h"
+#include "ds_value.h"
 
 namespace {
 
@@ -61,7 +61,8 @@ struct ds_system {
     void* blob32 = nullptr;
     std::vector<ds_param_block> blocks;
     int64_t nparams = 0;
-    WsLayout ws;
+    WsLayout ws;                      // forward-Laplacian chain, per walker
+    WsLayout wsv;                     // value chain, per group of PV walkers
     // block indices
     std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_pi, i_sg;
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
@@ -205,6 +206,25 @@ void build_layouts(ds_system* s) {
     }
     w.MOUT = mo; w.MINV = rup((int)mi, 16); w.DETS = rup((int)de, 16); w.TR = tr;
     w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR;
+    // value chain: the slot axis carries PV walkers (ds_value.h)
+    WsLayout& v = s->wsv;
+    const size_t PV = ds::PV;
+    v = w;
+    v.G = (size_t)S.N * S.ldk * PV;
+    v.MEAN = (size_t)S.nch * h1max * PV;
+    v.ZB = (size_t)h1max * PV;
+    for (int c = 0; c < S.nch; ++c) v.ZB = std::max(v.ZB, (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * PV);
+    v.H2 = (size_t)(PV / 5) * h2max * 5 * S.NP;
+    v.Q = (size_t)S.N * S.nparam_max * 2 * PV;
+    mo = 0;
+    for (int c = 0; c < 2; ++c) {
+        const size_t n = c == 0 ? S.n_up : S.n_dn;
+        v.mout_off[c] = mo;
+        mo += (size_t)S.K * n * n * 2 * PV;
+    }
+    v.MOUT = mo; v.MINV = 0; v.TR = 0;
+    v.DETS = w.DETS * PV;             // DETS stays per walker
+    v.per_walker = 2 * v.G + 2 * v.MEAN + v.ZB + 2 * v.H2 + v.Q + v.MOUT + v.DETS;
 }
 
 template <typename T> struct Carve {
@@ -243,6 +263,14 @@ template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
         case 19: f(std::integral_constant<int, 1>(), std::integral_constant<int, 19>()); return 0;
         default: return 1;
     }
+}
+
+// workgroup size and grid.z of k_jet_gemm<NB>: at most 1024/NB threads (= its launch bound) per workgroup
+inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz) {
+    const int nw = Nout / (16 * NB), wmax = 1024 / NB / 64;
+    const int wpb = nw < wmax ? nw : wmax;
+    *block = dim3(wpb * 64);
+    *gz = (unsigned)((nw + wpb - 1) / wpb);
 }
 
 enum Stop { STOP_NONE = 0, STOP_G0, STOP_G1, STOP_G2, STOP_G3, STOP_H2_0, STOP_H2_1, STOP_H2_2, STOP_MEAN0, STOP_MEAN1, STOP_Q,
@@ -296,7 +324,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             const bool res = K2 == K2o;
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
             ProfScope ps(s, DS_PROF_TWO_LAYER, st);
-#define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES>), grid, dim3(256), 0, st, S, c.H2[hi], K2, W2, b2, c.H2[hi ^ 1])
+#define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, false>), grid, dim3(256), 0, st, S, c.H2[hi], K2, W2, b2, c.H2[hi ^ 1])
             if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
             else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
 #undef DS_TWO
@@ -307,27 +335,28 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const bool res = Kh == Nout;
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
-            const dim3 block(Nout / (16 * NB) * 64);
+            dim3 block; unsigned gz;
+            gemm_geom(Nout, NB, &block, &gz);
             const size_t gws = (size_t)S.N * S.ldk * S.P, gts = (size_t)S.ldk * S.P;
             {
                 ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
                 // shared spin-mean term S (one tile per walker), then the N electron tiles with the fused epilogue
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(1, (unsigned)Bc), block, 0, st, (const T*)nullptr, (size_t)0,
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr, (size_t)0,
                                    (size_t)0, (const T*)nullptr, 0, c.MEAN[mi], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0, c.ZB,
                                    (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, (const T*)nullptr);
                 if (res)
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N, (unsigned)Bc), block, 0, st, c.G[gi], gws, gts,
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N, (unsigned)Bc, gz), block, 0, st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
                                        (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]));
                 else
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N, (unsigned)Bc), block, 0, st, c.G[gi], gws, gts,
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N, (unsigned)Bc, gz), block, 0, st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
                                        (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]));
             }
             if (l + 1 < S.n_layers) {
                 ProfScope ps(s, DS_PROF_LAYER_EPILOGUE, st);
                 hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)(((size_t)Nout * S.P + 255) / 256), S.nch, (unsigned)Bc),
-                                   dim3(256), 0, st, S, c.G[gi ^ 1], c.MEAN[mi ^ 1], Nout);
+                                   dim3(256), 0, st, S, c.G[gi ^ 1], c.MEAN[mi ^ 1], Nout, S.P);
             }
         });
         if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
@@ -342,12 +371,13 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     // orbitals: GEMM over the electrons of one spin, then envelope/phase product rule
     for (int sp = 0; sp < S.nch; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp], Kh = S.h1[S.n_layers];
-        if (OC > 1024) return fail("2 * n_s * n_det = %d orbital columns exceed 1024", OC);
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             {
                 ProfScope ps(s, DS_PROF_ORBITAL, st);
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(ns, (unsigned)Bc), dim3(OC / (16 * NB) * 64), 0, st,
+                dim3 block; unsigned gz;
+                gemm_geom(OC, NB, &block, &gz);
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(ns, (unsigned)Bc, gz), block, 0, st,
                                    c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
                                    blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, c.ZB,
                                    (size_t)ns * OC * S.P, OC, S.P, (const T*)nullptr, (const T*)nullptr);
@@ -365,7 +395,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
         ProfScope ps(s, DS_PROF_DET_INVERSE, st);
         hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp,
-                           c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp]);
+                           c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp], S.P, 1);
     }
     if (stop == STOP_MINV) return copy_out(dr, c.MINV, L.MINV * Bc, st);
     for (int sp = 0; sp < S.nch; ++sp) {
@@ -380,7 +410,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     } while (0)
         if (n <= 16) DS_TRACE(16, 16);
         else if (n <= 32) DS_TRACE(32, 8);
-        else if (n <= 64) DS_TRACE(64, 4);
+        else if (n <= 64) DS_TRACE(64, 2);      // LDS: (1 + SP) n^2 complex must stay below 160 KiB
         else return fail("n_s = %d > 64 electrons per spin is not supported", n);
 #undef DS_TRACE
     }
@@ -390,6 +420,128 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         ProfScope ps(s, DS_PROF_COMBINE, st);
         hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, c.TR, L.TR, L.tr_off[1], c.DETS, L.DETS,
                            L.dets_off[1], out_ke, out_logabs, out_phase);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// The value chain (log psi only) on `Bc` walkers = ceil(Bc / PV) groups; see ds_value.h.
+template <typename T>
+int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, hipStream_t st, T* out_logabs, T* out_phase,
+                    T** mout_ptr) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const WsLayout& L = s->wsv;
+    const int PV = ds::PV;
+    const int64_t ng = (Bc + PV - 1) / PV;
+    T* p = (T*)ws;
+    T* G[2]; T* MEAN[2]; T* H2[2];
+    G[0] = p; p += L.G * ng; G[1] = p; p += L.G * ng;
+    MEAN[0] = p; p += L.MEAN * ng; MEAN[1] = p; p += L.MEAN * ng;
+    T* ZB = p; p += L.ZB * ng;
+    H2[0] = p; p += L.H2 * ng; H2[1] = p; p += L.H2 * ng;
+    T* Q = p; p += L.Q * ng;
+    T* MOUT = p; p += L.MOUT * ng;
+    T* DETS = p; p += L.DETS * ng;
+    auto blk = [&](int i) { return params + s->blocks[i].offset; };
+    hipLaunchKernelGGL((ds::k_features_val<T>), dim3((unsigned)ng), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]), blk(s->i_sg[0]),
+                       blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), G[0], MEAN[0], H2[0], Q);
+    int gi = 0, hi = 0, mi = 0;
+    const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
+    for (int l = 0; l < S.n_layers; ++l) {
+        const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
+        hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, H2[hi], K2, G[gi], Kh);
+        if (l < S.n_double) {
+            const int K2o = S.h2[l + 1];
+            if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
+            dim3 grid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
+            const bool res = K2 == K2o;
+            const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
+#define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, true>), grid, dim3(256), 0, st, S, H2[hi], K2, W2, b2, H2[hi ^ 1])
+            if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
+            else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
+#undef DS_TWO
+        }
+        if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
+        const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
+        dim3 block; unsigned gz;
+        gemm_geom(Nout, 4, &block, &gz);
+        hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
+                           (const T*)nullptr, 0, MEAN[mi], (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
+                           (const T*)nullptr, (const T*)nullptr);
+        if (Kh == Nout)
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, 0, st, G[gi], gws, gts, blk(s->i_wloc[l]), Kloc,
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, G[gi ^ 1], (size_t)0, Nout, PV, ZB, blk(s->i_b[l]));
+        else
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 3>), dim3(S.N, (unsigned)ng, gz), block, 0, st, G[gi], gws, gts, blk(s->i_wloc[l]), Kloc,
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, G[gi ^ 1], (size_t)0, Nout, PV, ZB, blk(s->i_b[l]));
+        if (l + 1 < S.n_layers)
+            hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)(((size_t)Nout * PV + 255) / 256), S.nch, (unsigned)ng), dim3(256), 0, st,
+                               S, G[gi ^ 1], MEAN[mi ^ 1], Nout, PV);
+        gi ^= 1; mi ^= 1;
+        if (l < S.n_double) hi ^= 1;
+    }
+    for (int sp = 0; sp < S.nch; ++sp) {
+        const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp], Kh = S.h1[S.n_layers];
+        dim3 oblock; unsigned ogz;
+        gemm_geom(OC, 4, &oblock, &ogz);
+        hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, G[gi] + (size_t)i0 * S.ldk * PV,
+                           gws, gts, blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, ZB, (size_t)ns * OC * PV,
+                           OC, PV, (const T*)nullptr, (const T*)nullptr);
+        hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, ZB, (size_t)ns * OC * PV, Q, MOUT, sp,
+                           L.MOUT, L.mout_off[sp]);
+    }
+    if (mout_ptr) *mout_ptr = MOUT;
+    if (out_logabs || out_phase) {
+        const size_t dstride = s->ws.DETS;
+        for (int sp = 0; sp < S.nch; ++sp) {
+            const int n = sp == 0 ? S.n_up : S.n_dn;
+            size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
+            hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, MOUT, L.MOUT, L.mout_off[sp], sp,
+                               (T*)nullptr, (size_t)0, (size_t)0, DETS, dstride, s->ws.dets_off[sp], PV, PV);
+        }
+        hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, (const T*)nullptr, (size_t)0, (size_t)0, DETS, dstride,
+                           s->ws.dets_off[1], (T*)nullptr, out_logabs, out_phase);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int logpsi_impl(ds_system* s, const void* params, const void* x, int64_t B, void* out_logabs, void* out_phase, void* ws, int64_t ws_bytes,
+                hipStream_t st) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const int64_t cg = ws_bytes / (int64_t)(s->wsv.per_walker * sizeof(T));
+    if (cg < 1) return fail("workspace too small for the value chain: %lld bytes < %zu per group", (long long)ws_bytes, s->wsv.per_walker * sizeof(T));
+    const int64_t chunk = cg * ds::PV;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t Bc = std::min(chunk, B - b0);
+        int rc = run_value_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, ws, st, out_logabs ? (T*)out_logabs + b0 : nullptr,
+                                    out_phase ? (T*)out_phase + 2 * b0 : nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+template <typename T>
+int orbitals_impl(ds_system* s, const void* params, const void* x, int64_t B, void* out_up, void* out_dn, void* ws, int64_t ws_bytes,
+                  hipStream_t st) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const int64_t cg = ws_bytes / (int64_t)(s->wsv.per_walker * sizeof(T));
+    if (cg < 1) return fail("workspace too small for the value chain");
+    const int64_t chunk = cg * ds::PV;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t Bc = std::min(chunk, B - b0);
+        T* mout = nullptr;
+        int rc = run_value_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, ws, st, nullptr, nullptr, &mout);
+        if (rc) return rc;
+        for (int sp = 0; sp < S.nch; ++sp) {
+            const int n = sp == 0 ? S.n_up : S.n_dn;
+            T* o = (T*)(sp == 0 ? out_up : out_dn);
+            if (!o) continue;
+            const size_t per = (size_t)S.K * n * n * 2;
+            hipLaunchKernelGGL((ds::k_gather_val<T>), dim3((unsigned)((per + 255) / 256), (unsigned)Bc), dim3(256), 0, st, mout, s->wsv.MOUT,
+                               s->wsv.mout_off[sp], per, (long)b0, (long)Bc, o);
+        }
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -489,7 +641,8 @@ int64_t ds_workspace_bytes(const ds_system* s, int64_t B) {
     if (!s) return -1;
     const int64_t esz = s->dtype == 0 ? 8 : 4;
     const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 1024);
-    return (int64_t)s->ws.per_walker * esz * chunk + 256;
+    const int64_t groups = std::min<int64_t>((std::max<int64_t>(B, 1) + ds::PV - 1) / ds::PV, 64);
+    return std::max((int64_t)s->ws.per_walker * esz * chunk, (int64_t)s->wsv.per_walker * esz * groups) + 256;
 }
 
 int ds_local_energy(ds_system* s, const void* params, const void* x, int64_t B, void* out_ke, void* out_ewald, void* out_logabs,
@@ -503,8 +656,11 @@ int ds_local_energy(ds_system* s, const void* params, const void* x, int64_t B, 
 
 int ds_logpsi(ds_system* s, const void* params, const void* x, int64_t B, void* out_logabs, void* out_phase, void* ws,
               int64_t ws_bytes, void* stream) {
-    // round 1: the value rides in slot 0 of the forward-Laplacian chain
-    return ds_local_energy(s, params, x, B, nullptr, nullptr, out_logabs, out_phase, ws, ws_bytes, stream);
+    if (!s || !params || !x || !ws) return fail("null argument");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return s->dtype == 0 ? logpsi_impl<double>(s, params, x, B, out_logabs, out_phase, ws, ws_bytes, st)
+                         : logpsi_impl<float>(s, params, x, B, out_logabs, out_phase, ws, ws_bytes, st);
 }
 
 int ds_ewald(ds_system* s, const void* x, int64_t B, void* out, void* stream) {
@@ -580,30 +736,10 @@ int ds_mh_accept(ds_system* s, void* x1, void* lp1, const void* x2, const void* 
 int ds_orbitals(ds_system* s, const void* params, const void* x, int64_t B, void* out_up, void* out_dn, void* ws, int64_t ws_bytes,
                 void* stream) {
     if (!s || !params || !x || !ws || !out_up) return fail("null argument");
-    if (s->dtype != 0) return fail("ds_orbitals: f64 only in this build");
+    if (B <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const ds::SysDev<double>& S = s->sd;
-    const int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(double));
-    if (chunk < 1) return fail("workspace too small");
-    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
-        const int64_t Bc = std::min(chunk, B - b0);
-        DumpReq<double> dr{STOP_MOUT, nullptr, 0, 0};
-        // run up to MOUT without copying (cap 0), then gather slot 0
-        dr.out = (double*)ws; dr.cap = 0;
-        int rc = run_chain<double>(s, (const double*)params, (const double*)x + b0 * 3 * S.N, Bc, ws, st, nullptr, nullptr, nullptr, &dr);
-        if (rc) return rc;
-        Carve<double> c = carve<double>(s, ws, Bc);
-        for (int sp = 0; sp < S.nch; ++sp) {
-            const int n = sp == 0 ? S.n_up : S.n_dn;
-            double* o = (double*)(sp == 0 ? out_up : out_dn);
-            if (!o) continue;
-            const size_t per = (size_t)S.K * n * n * 2;
-            hipLaunchKernelGGL((ds::k_gather_slot0<double>), dim3((unsigned)((per + 255) / 256), (unsigned)Bc), dim3(256), 0, st,
-                               c.MOUT, s->ws.MOUT, s->ws.mout_off[sp], per, S.P, o + b0 * per);
-        }
-    }
-    HIP_OK(hipGetLastError());
-    return 0;
+    return s->dtype == 0 ? orbitals_impl<double>(s, params, x, B, out_up, out_dn, ws, ws_bytes, st)
+                         : orbitals_impl<float>(s, params, x, B, out_up, out_dn, ws, ws_bytes, st);
 }
 
 int64_t ds_debug_stage(ds_system* s, const void* params, const void* x, int64_t B, const char* stage, void* out, int64_t out_elems,

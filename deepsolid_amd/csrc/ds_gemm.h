@@ -1,25 +1,26 @@
 // ds_gemm.h -- the dense contraction of the chain and its element-wise epilogues.
 //
-//   k_jet_gemm        Z[tile][n][slot] = sum_k W[k][n] * X[tile][k][slot]      (fp64/fp32 MFMA)
-//   k_layer_epilogue  h_i <- res(h_i, tanh-jet(Z_i + S)) and the spin means of the new h
+//   k_jet_gemm          Z[tile][n][slot] = sum_k W[k][n] * X[tile][k][slot]      (fp64/fp32 MFMA)
+//                       with an optional fused one-electron-layer epilogue (tanh chain rule, residual)
+//   k_spin_mean         spin means of the new one-electron stream
 //   k_orbital_epilogue  M = (Re,Im)(Phi) * q  with the product rule on the jets
 //
-// The GEMM is kept free of any epilogue arithmetic so that it needs only its accumulators and
-// two k-steps of operands in registers (two waves per SIMD); everything latency-sensitive
-// (tanh chain rule, residual, means) runs in a separate bandwidth-bound kernel with many waves.
+// The GEMM main loop needs only its accumulators and two k-steps of operands in registers, which
+// keeps two waves per SIMD resident: one wave's loads / epilogue hide behind the other's MFMAs.
 #pragma once
 #include "ds_kernels.h"
 
 namespace ds {
 
-// One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x all Nout
-// output features; wave w owns features [16*NB*w, 16*NB*(w+1)).  Tiles 0..n_tiles-1 use (X, W, K);
+// One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x up to 1024/NB
+// output features (grid.z walks further column blocks); every wave owns 16*NB features.  Tiles 0..n_tiles-1 use (X, W, K);
 // the optional extra tile (blockIdx.x == n_tiles) uses (X2, W2, K2): the shared spin-mean term.
 //   X  : [walker][tile][ldx rows][P]      W : [K][Nout]      Z : [walker][tile (+1)][Nout][P]
 //   EPI = 0: store the raw products Z.
 //   EPI = 1/2: fused one-electron-layer epilogue (network.py:524-528): z = Z + S + b, tanh chain rule on
 //              the jets, (EPI = 2) residual with the layer input rows, store into the next layer's G.
 //              S : [walker][Nout][P] shared spin-mean term, Gout : [walker][tile][ldo rows][P].
+//   EPI = 3/4: value chain (slots = walkers): plain tanh(Z + S + b) without / with residual.
 template <typename T, int NB, int ST, int EPI>
 __global__ void __launch_bounds__(1024 / NB, (NB == 4 ? 2 : 1))
 k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride, const T* __restrict__ W, int K,
@@ -28,7 +29,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
            const T* __restrict__ bias) {
     typedef typename Acc4<T>::type acc_t;
     const int tile = blockIdx.x, w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lr = lane & 15, lq = lane >> 4, n0 = wave * 16 * NB;
+    const int lr = lane & 15, lq = lane >> 4, n0 = (blockIdx.z * (blockDim.x >> 6) + wave) * 16 * NB;
+    if (n0 >= Nout) return;                      // column blocks beyond Nout (grid.z rounds up)
     const T* Xp;
     const T* Wp;
     int nks;
@@ -113,11 +115,20 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 T ss = 0;
 #pragma unroll
                 for (int s = 0; s < ST; ++s) z[s] = Sp[(size_t)n * P + 16 * s];
-                if (EPI == 2) {
+                if (EPI == 2 || EPI == 4) {
 #pragma unroll
                     for (int s = 0; s < ST; ++s) hv[s] = Gi[(size_t)n * P + 16 * s];
                 }
                 const T bn = bias[n];
+                if (EPI >= 3) {
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) {
+                        T o = ds_tanh(z[s] + acc[a][s][r] + bn);
+                        if (EPI == 4) o = (hv[s] + o) * rs2;
+                        Go[(size_t)n * P + 16 * s] = o;
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int s = 0; s < ST; ++s) {
                     z[s] += acc[a][s][r];
@@ -140,8 +151,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 
 // spin means of the new one-electron stream:  MEAN[w][sp][n][slot] = mean_{i in sp} G[w][i][n][slot]
 template <typename T>
-__global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restrict__ G, T* __restrict__ MEANout, int Nout) {
-    const int w = blockIdx.z, sp = blockIdx.y, P = S.P;
+__global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restrict__ G, T* __restrict__ MEANout, int Nout, int P) {
+    const int w = blockIdx.z, sp = blockIdx.y;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (size_t)Nout * P) return;
     const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn;
@@ -150,56 +161,6 @@ __global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restr
 #pragma unroll 4
     for (int i = 0; i < ns; ++i) acc += g[(size_t)i * S.ldk * P];
     MEANout[(((size_t)w * S.nch + sp) * Nout) * P + e] = acc / T(ns);
-}
-
-// tanh chain rule on the jets + residual + spin means (network.py:521-533).
-//   Z : [walker][N+1][Nout][P]  (tile N = shared term S);   Gin/Gout : [walker][N][ldk][P]
-//   16 lanes own one feature row (its P slots, ST per lane); a block of 256 threads owns 16 rows
-//   of one walker and walks the electrons, so the means are accumulated in registers.
-template <typename T, int ST, bool RES>
-__global__ void __launch_bounds__(256) k_layer_epilogue(SysDev<T> S, const T* __restrict__ Z, const T* __restrict__ bias,
-                                                        const T* __restrict__ Gin, T* __restrict__ Gout,
-                                                        T* __restrict__ MEANout, int Nout) {
-    const int w = blockIdx.y, tid = threadIdx.x, lr = tid & 15, n = blockIdx.x * 16 + (tid >> 4);
-    const int N = S.N, P = S.P, lane = tid & 63, base = lane & 48;
-    const T rs2 = T(0.70710678118654752440);
-    const T* Zw = Z + (size_t)w * (N + 1) * Nout * P + (size_t)n * P + lr;
-    T sv[ST], macc[ST];
-#pragma unroll
-    for (int s = 0; s < ST; ++s) {
-        sv[s] = Zw[(size_t)N * Nout * P + 16 * s];
-        macc[s] = 0;
-    }
-    if (lr == 0) sv[0] += bias[n];
-    for (int i = 0; i < N; ++i) {
-        T z[ST];
-        T ss = 0;
-#pragma unroll
-        for (int s = 0; s < ST; ++s) {
-            z[s] = Zw[(size_t)i * Nout * P + 16 * s] + sv[s];
-            if (16 * s + lr >= 2) ss += z[s] * z[s];
-        }
-        ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
-        const T z0 = __shfl(z[0], base), zL = __shfl(z[0], base | 1);
-        const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
-        const size_t go = ((size_t)(w * N + i) * S.ldk + n) * P + lr;
-#pragma unroll
-        for (int s = 0; s < ST; ++s) {
-            T o = d1 * z[s];
-            if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
-            if (RES) o = (Gin[go + 16 * s] + o) * rs2;
-            Gout[go + 16 * s] = o;
-            macc[s] += o;
-        }
-        const bool last_up = (i == S.n_up - 1), last = (i == N - 1);
-        if (last_up || last) {
-            const int sp = last_up ? 0 : 1;
-            const T inv_ns = T(1) / T(sp == 0 ? S.n_up : S.n_dn);
-            T* Mo = MEANout + (((size_t)w * S.nch + sp) * Nout + n) * P + lr;
-#pragma unroll
-            for (int s = 0; s < ST; ++s) { Mo[16 * s] = macc[s] * inv_ns; macc[s] = 0; }
-        }
-    }
 }
 
 // Orbital head epilogue (network.py:543-557): complex phi = (Phi[p], Phi[nparam + p]),

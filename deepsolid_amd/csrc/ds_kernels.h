@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
 //     MFMA, C[n][(c,pair)] ; the five jet components of a pair sit in five accumulator tiles of the
 //     same lane, so the tanh chain rule is lane-local.
 // =====================================================================================
-template <typename T, int NT2, bool RES>
+template <typename T, int NT2, bool RES, bool VAL>
 __global__ void __launch_bounds__(256) k_two_layer(SysDev<T> S, const T* __restrict__ Hin, int Kin, const T* __restrict__ W,
                                                    const T* __restrict__ bias, T* __restrict__ Hout) {
     typedef typename Acc4<T>::type acc_t;
@@ -235,6 +235,9 @@ __global__ void __launch_bounds__(256) k_two_layer(SysDev<T> S, const T* __restr
             const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
             const T z1 = acc[a][1][r], z2 = acc[a][2][r], z3 = acc[a][3][r], z4 = acc[a][4][r];
             T o[5] = {y, d1 * z1, d1 * z2, d1 * z3, d1 * z4 + d2 * 2 * (z1 * z1 + z2 * z2 + z3 * z3)};
+            if (VAL) {   // value chain: the five columns are five independent walkers
+                o[1] = ds_tanh(z1 + bias[n]); o[2] = ds_tanh(z2 + bias[n]); o[3] = ds_tanh(z3 + bias[n]); o[4] = ds_tanh(z4 + bias[n]);
+            }
             for (int c = 0; c < 5; ++c) {
                 T v = o[c];
                 if (RES) v = (Hw[(size_t)(n * 5 + c) * NP] + v) * rs2;
@@ -252,13 +255,16 @@ __global__ void __launch_bounds__(256) k_two_layer(SysDev<T> S, const T* __restr
 template <typename T>
 __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                     int sp, T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
-                                                    T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+                                                    T* __restrict__ DETS, size_t dets_stride, size_t dets_off, int P,
+                                                    int cols_per_group) {
+    // forward-Laplacian chain: P = S.P, cols_per_group = 1 (value = slot 0 of walker w);
+    // value chain: P = PV, cols_per_group = PV (value of walker w = column w % PV of group w / PV)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Cx<T>* aug = reinterpret_cast<Cx<T>*>(smem_raw);   // [n][2n]
     const int kdet = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
-    const int P = S.P, n = sp == 0 ? S.n_up : S.n_dn, n2 = 2 * n;
+    const int n = sp == 0 ? S.n_up : S.n_dn, n2 = 2 * n;
     int* piv_p = reinterpret_cast<int*>(aug + n * n2);  // all LDS in the one dynamic region (16-B aligned base)
-    const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
+    const T* Mw = MOUT + (size_t)(w / cols_per_group) * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P + w % cols_per_group;
     for (int idx = lane; idx < n * n; idx += 64) {
         const int r = idx / n, c = idx % n;
         aug[r * n2 + c] = Cx<T>(Mw[(size_t)(idx * 2) * P], Mw[(size_t)(idx * 2 + 1) * P]);
@@ -307,11 +313,13 @@ __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __rest
             if (r != j) aug[r * n2 + j] = Cx<T>(0, 0);
         __syncthreads();
     }
-    T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
-    for (int idx = lane; idx < n * n; idx += 64) {
-        const int r = idx / n, c = idx % n;
-        Iw[2 * idx] = aug[r * n2 + n + c].re;
-        Iw[2 * idx + 1] = aug[r * n2 + n + c].im;
+    if (MINV) {
+        T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
+        for (int idx = lane; idx < n * n; idx += 64) {
+            const int r = idx / n, c = idx % n;
+            Iw[2 * idx] = aug[r * n2 + n + c].re;
+            Iw[2 * idx + 1] = aug[r * n2 + n + c].im;
+        }
     }
     if (lane == 0) {
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
@@ -430,7 +438,7 @@ __global__ void __launch_bounds__(64) k_combine(SysDev<T> S, const T* __restrict
     }
     const Cx<T> sinv = cx_inv(sum);
     Cx<T> ke(0, 0);
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < K && out_ke; ++k) {
         // sum_d (d_d log D_k)^2 over direction slots, complex square
         Cx<T> g2(0, 0);
         for (int d = 2 + lane; d < S.D; d += 64) {

@@ -1,0 +1,157 @@
+// ds_value.h -- value-only instantiation of the chain (log psi / orbitals for Metropolis).
+//
+// Same buffers and the same GEMM as the forward-Laplacian chain, but the contiguous "slot" axis
+// carries PV = 80 different WALKERS (a "group") instead of the 3N+2 jet components of one walker:
+//   G    [group][electron][row k][PV]     MEAN [group][spin][k][PV]     S [group][n][PV]
+//   H2   [group*16 + c/5][k2][c%5][NP]    (the pair-stream kernel handles five columns per lane)
+//   Q    [group][electron][p][re,im][PV]  envelope * Bloch phase (values)
+//   MOUT [group][spin][det][elec][orb][re,im][PV]
+// Walker column c of group g is walker min(g*PV + c, B-1) (the tail of the last group repeats the
+// last walker; its results are never copied out).
+#pragma once
+#include "ds_gemm.h"
+
+namespace ds {
+
+constexpr int PV = 80;
+
+// value of [sd, rel_x, rel_y, rel_z] (network.py:207-224), no derivatives
+template <typename T>
+__device__ __forceinline__ void nu_distance_val(const T r[3], const T* __restrict__ av, const T* __restrict__ bv, int L,
+                                                T out[4]) {
+    const T pi = T(DS_PI);
+    T f[6], g[6];
+    for (int l = 0; l < L; ++l) {
+        T w = r[0] * bv[3 * l] + r[1] * bv[3 * l + 1] + r[2] * bv[3 * l + 2];
+        w = w - ds_floor((w + pi) / (2 * pi)) * 2 * pi;
+        const T aw = ds_abs(w / pi);
+        f[l] = ds_abs(w) * (1 - aw * aw * aw / 4);
+        g[l] = w * (1 - T(1.5) * aw + T(0.5) * aw * aw);
+    }
+    T s2 = 0;
+    for (int l = 0; l < L; ++l) {
+        const T n2 = av[3 * l] * av[3 * l] + av[3 * l + 1] * av[3 * l + 1] + av[3 * l + 2] * av[3 * l + 2];
+        s2 += n2 * f[l] * f[l];
+        for (int m = 0; m < L; ++m)
+            if (m != l) s2 += (av[3 * l] * av[3 * m] + av[3 * l + 1] * av[3 * m + 1] + av[3 * l + 2] * av[3 * m + 2]) * g[l] * g[m];
+    }
+    out[0] = ds_sqrt(s2);
+    for (int c = 0; c < 3; ++c) {
+        T rc = 0;
+        for (int l = 0; l < L; ++l) rc += av[3 * l + c] * g[l];
+        out[1 + c] = rc;
+    }
+}
+
+// grid (groups), block 256.  Phase 1 writes the one-electron features and the pair features,
+// phase 2 (after a block barrier; same CU, so the rows just written are visible) the spin means and Q.
+template <typename T>
+__global__ void __launch_bounds__(256) k_features_val(SysDev<T> S, const T* __restrict__ x, long B, const T* __restrict__ env_pi0,
+                                                      const T* __restrict__ env_sg0, const T* __restrict__ env_pi1,
+                                                      const T* __restrict__ env_sg1, T* __restrict__ G, T* __restrict__ MEAN,
+                                                      T* __restrict__ H2, T* __restrict__ Q) {
+    const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int N = S.N, A = S.A, NP = S.NP, K1 = 4 * A;
+    T* Gw = G + (size_t)g * N * S.ldk * PV;
+    auto walker = [&](int c) { long wi = (long)g * PV + c; return wi < B ? wi : B - 1; };
+    for (int idx = tid; idx < N * A * PV; idx += nt) {
+        const int c = idx % PV, a = (idx / PV) % A, i = idx / (PV * A);
+        const T* xp = x + (size_t)walker(c) * 3 * N + 3 * i;
+        T r[3] = {xp[0], xp[1], xp[2]}, o[3], wr[3], f[4];
+        wrap_point(r, S.prim_a, S.prim_ainv, o, wr);
+        for (int k = 0; k < 3; ++k) o[k] -= S.atoms[3 * a + k];
+        nu_distance_val(o, S.prim_AV, S.prim_BV, S.L, f);
+        for (int k = 0; k < 4; ++k) Gw[((size_t)i * S.ldk + 4 * a + k) * PV + c] = f[k];
+    }
+    for (int idx = tid; idx < PV * NP; idx += nt) {
+        const int q = idx % NP, c = idx / NP;
+        const int e = q / N, j = q % N;
+        T f[4] = {0, 0, 0, 0};
+        if (q < N * N && e != j) {
+            const T* xw = x + (size_t)walker(c) * 3 * N;
+            T rj[3] = {xw[3 * j], xw[3 * j + 1], xw[3 * j + 2]}, re[3] = {xw[3 * e], xw[3 * e + 1], xw[3 * e + 2]}, oj[3], oe[3], wr[3];
+            wrap_point(rj, S.sim_a, S.sim_ainv, oj, wr);
+            wrap_point(re, S.sim_a, S.sim_ainv, oe, wr);
+            for (int k = 0; k < 3; ++k) oj[k] -= oe[k];
+            nu_distance_val(oj, S.sim_AV, S.sim_BV, S.L, f);
+        }
+        T* Hw = H2 + (size_t)(g * (PV / 5) + c / 5) * S.h2[0] * 5 * NP;
+        for (int k = 0; k < 4; ++k) Hw[(size_t)(k * 5 + c % 5) * NP + q] = f[k];
+    }
+    __syncthreads();
+    T* Mw = MEAN + (size_t)g * S.nch * K1 * PV;
+    for (int idx = tid; idx < S.nch * K1 * PV; idx += nt) {
+        const int c = idx % PV, k = (idx / PV) % K1, s = idx / (PV * K1);
+        const int i0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
+        T v = 0;
+        for (int i = i0; i < i0 + ns; ++i) v += Gw[((size_t)i * S.ldk + k) * PV + c];
+        Mw[idx] = v / T(ns);
+    }
+    T* Qw = Q + (size_t)g * N * S.nparam_max * 2 * PV;
+    for (int idx = tid; idx < N * S.nparam_max * PV; idx += nt) {
+        const int c = idx % PV, p = (idx / PV) % S.nparam_max, i = idx / (PV * S.nparam_max);
+        const int s = spin_of(i, S.n_up), ns = s == 0 ? S.n_up : S.n_dn;
+        if (p >= S.nparam[s]) continue;
+        const T* pi_ = s == 0 ? env_pi0 : env_pi1;
+        const T* sg_ = s == 0 ? env_sg0 : env_sg1;
+        T e = 0;
+        for (int a = 0; a < A; ++a) {
+            const T sd = Gw[((size_t)i * S.ldk + 4 * a) * PV + c];
+            e += pi_[a * S.nparam[s] + p] * ds_exp(-ds_abs(sd * sg_[a * S.nparam[s] + p]));
+        }
+        const T* kv = S.klist[s] + 3 * (p % ns);
+        const T* xp = x + (size_t)walker(c) * 3 * N + 3 * i;
+        T sn, cs;
+        ds_sincos(kv[0] * xp[0] + kv[1] * xp[1] + kv[2] * xp[2], &sn, &cs);
+        Qw[((size_t)(i * S.nparam_max + p) * 2) * PV + c] = e * cs;
+        Qw[((size_t)(i * S.nparam_max + p) * 2 + 1) * PV + c] = e * sn;
+    }
+}
+
+// rows [row0, row0 + nch*K2) of G: mean over the partners j of spin s of h2[j][e] (values)
+template <typename T>
+__global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __restrict__ H2, int K2, T* __restrict__ G, int row0) {
+    const int e = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, N = S.N, NP = S.NP;
+    T* Ge = G + ((size_t)(g * N + e) * S.ldk + row0) * PV;
+    for (int idx = tid; idx < S.nch * K2 * PV; idx += blockDim.x) {
+        const int c = idx % PV, k = (idx / PV) % K2, s = idx / (PV * K2);
+        const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
+        const T* hp = H2 + ((size_t)(g * (PV / 5) + c / 5) * K2 * 5 + (size_t)(k * 5 + c % 5)) * NP + (size_t)e * N;
+        T v = 0;
+        for (int j = j0; j < j0 + ns; ++j) v += hp[j];
+        Ge[idx] = v / T(ns);
+    }
+}
+
+// M = phi * q (values).  PHI [group][elec in spin][ocols][PV], grid (n_s, groups), block 256
+template <typename T>
+__global__ void __launch_bounds__(256) k_orbital_epilogue_val(SysDev<T> S, const T* __restrict__ PHI, size_t phi_group_stride,
+                                                              const T* __restrict__ Q, T* __restrict__ MOUT, int sp,
+                                                              size_t mout_stride, size_t mout_off) {
+    const int ii = blockIdx.x, g = blockIdx.y, N = S.N, OC = S.ocols[sp];
+    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn, nparam = S.nparam[sp], i = i0 + ii;
+    const T* Pw = PHI + (size_t)g * phi_group_stride + (size_t)ii * OC * PV;
+    const T* Qw = Q + ((size_t)(g * N + i) * S.nparam_max) * 2 * PV;
+    T* Mw = MOUT + (size_t)g * mout_stride + mout_off;
+    for (int idx = threadIdx.x; idx < nparam * PV; idx += blockDim.x) {
+        const int c = idx % PV, p = idx / PV;
+        const Cx<T> phi(Pw[(size_t)p * PV + c], Pw[(size_t)(nparam + p) * PV + c]);
+        const Cx<T> q(Qw[(size_t)(p * 2) * PV + c], Qw[(size_t)(p * 2 + 1) * PV + c]);
+        const Cx<T> v = phi * q;
+        T* mo = Mw + (((size_t)((p / ns) * ns + ii) * ns + p % ns) * 2) * PV + c;
+        mo[0] = v.re;
+        mo[PV] = v.im;
+    }
+}
+
+// MOUT (value chain) -> dense (B, K, n, n, 2) orbital matrices (network.py:601 'eval_mats')
+template <typename T>
+__global__ void k_gather_val(const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off, size_t per, long w0, long nw,
+                             T* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const long w = blockIdx.y;                       // walker within this chunk
+    if (idx >= per || w >= nw) return;
+    out[(size_t)(w0 + w) * per + idx] = MOUT[(size_t)(w / PV) * mout_stride + mout_off + idx * PV + w % PV];
+}
+
+}  // namespace ds

@@ -144,7 +144,7 @@ def test_stages_vs_forward_laplacian_oracle(name):
             off += sysd.n_det * ns * ns * 2 * P
 
 
-@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist'])
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'])
 def test_logpsi_and_orbitals_vs_reference_vectors(name):
     from deepsolid_amd import network
     fx, cell, klist, net_kw, params = load_case(name)
@@ -193,3 +193,18 @@ def test_local_energy_vs_oracle(name):
             assert abs(ke[b] - fx['ke_fd'][b]) < 10 * float(fx['ke_fd_tol']) * max(1.0, abs(ke[b]))
     with pytest.raises(ValueError):
         hamiltonian.local_energy_seperate(net.apply, cell, mode='nope')
+
+
+@pytest.mark.parametrize('name', ['graphene', 'diamond'])
+def test_large_cells_local_energy_vs_forward_laplacian_oracle(name):
+    """48 and 96 electrons (BASELINE configs 4 and 5 geometry, f64): generic tile instantiations."""
+    from deepsolid_amd import hamiltonian, network
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    x = torch.as_tensor(fx['x'][:1], device='cuda')
+    net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(dp, x)
+    ref = complex(ofl.stages(p_cpu, tt(fx['x'][0]), klist, cell, net_kw)['ke'])
+    assert abs(complex(ke[0].cpu()) - ref) < 1e-8 * max(1.0, abs(ref))
+    assert abs(float(ew[0].cpu()) - fx['ewald'][0].sum()) < 1e-8

@@ -48,3 +48,18 @@ if args.check:
         ref = complex(ofl.stages(p, torch.as_tensor(x_np[b]), klist, cell, net_kw)['ke'])
         errs.append(abs(complex(ke[b].cpu()) - ref) / max(1.0, abs(ref)))
     print(f'  max rel |dKE| vs oracle over {args.check} walkers: {max(errs):.3e}')
+# value chain: log psi and one mcmc_step (20 moves)
+from deepsolid_amd import qmc
+slog = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', dtype=dtype, **net_kw)
+slog.apply(params, x); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    lp = slog.apply(params, x)
+torch.cuda.synchronize()
+print(f'  logpsi (value chain): {(time.perf_counter() - t0) / args.steps * 1e3:.2f} ms per batch')
+step = qmc.make_mcmc_step(slog.apply, args.batch, cell.a, steps=20)
+xx, pm = step(params, x, 1, 0.02); torch.cuda.synchronize()
+t0 = time.perf_counter()
+xx, pm = step(params, x, 2, 0.02)
+torch.cuda.synchronize()
+print(f'  mcmc_step (20 moves): {(time.perf_counter() - t0) * 1e3:.1f} ms, pmove = {float(pm):.3f}')
