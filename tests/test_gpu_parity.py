@@ -208,3 +208,31 @@ def test_large_cells_local_energy_vs_forward_laplacian_oracle(name):
     ref = complex(ofl.stages(p_cpu, tt(fx['x'][0]), klist, cell, net_kw)['ke'])
     assert abs(complex(ke[0].cpu()) - ref) < 1e-8 * max(1.0, abs(ref))
     assert abs(float(ew[0].cpu()) - fx['ewald'][0].sum()) < 1e-8
+
+
+@pytest.mark.parametrize('name', ['lih', 'bcc_li', 'diamond'])
+def test_float32_chain_vs_float64_oracle(name):
+    """fp32 instantiation (BASELINE config 5 is fp32; CDNA4 has no TF32, v_mfma_f32_16x16x4_f32 is
+    exact f32).  Tolerances are f32-roundoff class: log|psi| 2e-3 absolute (sums over up to 96
+    log-dets), local kinetic energy 2e-3 relative to max(1, |E_kin|)."""
+    from deepsolid_amd import hamiltonian, network
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v]
+          for k, v in params.items()}
+    p_cpu = onet.params_to_torch(params)
+    nb = 2
+    x = torch.as_tensor(fx['x'][:nb], dtype=torch.float32, device='cuda')
+    ps = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_phase_and_slogdet',
+                                      dtype=torch.float32, **net_kw)
+    phase, logabs = ps.apply(dp, x)
+    assert logabs.dtype == torch.float32
+    np.testing.assert_allclose(logabs.cpu().numpy(), fx['logabs'][:nb], atol=2e-3)
+    assert np.abs(phase.cpu().numpy() - fx['phase'][:nb]).max() < 5e-3
+    ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', dtype=torch.float32, **net_kw)
+    ke, ew = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, x)
+    for b in range(nb):
+        # the f64 oracle evaluated at the f32-rounded walker the kernel actually saw
+        xb = x[b].cpu().double()
+        ref = complex(ofl.stages(p_cpu, xb, klist, cell, net_kw)['ke'])
+        assert abs(complex(ke[b].cpu()) - ref) < 2e-3 * max(1.0, abs(ref)), (complex(ke[b].cpu()), ref)
+    assert np.abs(ew.cpu().numpy() - fx['ewald'][:nb].sum(-1)).max() < 2e-3 * max(1.0, np.abs(fx['ewald'][:nb].sum(-1)).max())
