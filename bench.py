@@ -28,12 +28,13 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {torch.float64: 78.6, torch.float32: 157.3}   # MI355X dense matrix = vector peak (datasheet)
 
 
-def layer_flops(n_elec, kloc, ksh, nout):
-    """Algorithmic FLOPs of one one-electron-stream layer per walker in the forward-Laplacian
-    formulation: D = 3N+2 jet slots per scalar; per-electron rows [h_i | m2_i] (kloc)
-    and the spin-mean rows shared by all electrons (ksh), multiply-add = 2."""
+def layer_flops(n_elec, kloc, nout):
+    """Algorithmic FLOPs of the dominant kernel per walker: the N electron tiles of one hidden
+    one-electron-stream layer in the forward-Laplacian formulation:
+    D = 3N+2 jet slots per scalar, per-electron rows [h_i | mean_j h2_ji] (kloc), multiply-add = 2.
+    (The spin-mean term shared by all electrons is a separate, 15x smaller launch.)"""
     d = 3 * n_elec + 2
-    return 2.0 * n_elec * d * kloc * nout + 2.0 * d * ksh * nout
+    return 2.0 * n_elec * d * kloc * nout
 
 
 def log(msg):
@@ -141,7 +142,7 @@ def main():
     h1 = net_kw['hidden_dims'][0][0]
     h2 = net_kw['hidden_dims'][0][1]
     nch = 2 if cell.nelec[1] else 1
-    f_layer = layer_flops(n_e, h1 + nch * h2, nch * h1, h1)
+    f_layer = layer_flops(n_e, h1 + nch * h2, h1)
     ms_hidden, n_launch = prof['single_hidden']
     n_hidden = len(net_kw['hidden_dims']) - 1
     flops_total = f_layer * args.batch * n_hidden * args.steps           # this rank, timed region
@@ -156,7 +157,7 @@ def main():
                                f'(E_kin forward-Laplacian + Ewald), default detnet ((256,32),)*3, 8 dets',
                    'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': f'walker-dp{world}'},
         'energy_mean_ha': float(loss), 'energy_imag_ha': float(aux.imaginary), 'variance': float(aux.variance),
-        'roofline': {'bound': 'mfma', 'kernel': 'k_single_layer (hidden one-electron layers, K=%d+%d shared)' % (h1 + nch * h2, nch * h1),
+        'roofline': {'bound': 'mfma', 'kernel': 'k_jet_gemm<%s,4,5,2> (hidden one-electron layers: K=%d MFMA GEMM + fused tanh-jet epilogue)' % ('double' if dtype == torch.float64 else 'float', h1 + nch * h2),
                      'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                      'traffic': None, 'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch,
                      'flops_per_walker_layer': f_layer},

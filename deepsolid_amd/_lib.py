@@ -58,7 +58,7 @@ SIGNATURES = {
 }
 
 PROF_KINDS = ('features', 'm2_expand', 'two_layer', 'single_first', 'single_hidden', 'orbital', 'det_inverse',
-              'det_trace', 'combine', 'ewald', 'layer_epilogue', 'orbital_epilogue')
+              'det_trace', 'combine', 'ewald', 'spin_mean', 'orbital_epilogue', 'shared_term')
 
 _lib = None
 

@@ -339,11 +339,15 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             gemm_geom(Nout, NB, &block, &gz);
             const size_t gws = (size_t)S.N * S.ldk * S.P, gts = (size_t)S.ldk * S.P;
             {
-                ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
-                // shared spin-mean term S (one tile per walker), then the N electron tiles with the fused epilogue
+                // shared spin-mean term S (one tile per walker) ...
+                ProfScope ps(s, DS_PROF_SHARED_TERM, st);
                 hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr, (size_t)0,
                                    (size_t)0, (const T*)nullptr, 0, c.MEAN[mi], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0, c.ZB,
                                    (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, (const T*)nullptr);
+            }
+            {
+                // ... then the N electron tiles with the fused epilogue
+                ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
                 if (res)
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N, (unsigned)Bc, gz), block, 0, st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],

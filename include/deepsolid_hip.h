@@ -170,9 +170,10 @@ int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_
 #define DS_PROF_DET_TRACE 7
 #define DS_PROF_COMBINE 8
 #define DS_PROF_EWALD 9
-#define DS_PROF_LAYER_EPILOGUE 10
+#define DS_PROF_LAYER_EPILOGUE 10  /* k_spin_mean */
 #define DS_PROF_ORBITAL_EPILOGUE 11
-#define DS_PROF_KINDS 12
+#define DS_PROF_SHARED_TERM 12    /* k_jet_gemm<.,0> of the per-walker spin-mean term S = W_sh^T MEAN */
+#define DS_PROF_KINDS 13
 int ds_profile_enable(ds_system* sys, int on);
 int ds_profile_read(ds_system* sys, double* ms_total, int64_t* launches);
 
