@@ -339,11 +339,16 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             gemm_geom(Nout, NB, &block, &gz);
             const size_t gws = (size_t)S.N * S.ldk * S.P, gts = (size_t)S.ldk * S.P;
             {
-                // shared spin-mean term S (one tile per walker) ...
+                // shared spin-mean term S (one tile per walker): layer 0 from the MEAN buffer of k_features,
+                // hidden layers straight from the electron rows of G (means formed on the fly)
                 ProfScope ps(s, DS_PROF_SHARED_TERM, st);
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr, (size_t)0,
-                                   (size_t)0, (const T*)nullptr, 0, c.MEAN[mi], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0, c.ZB,
-                                   (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, (const T*)nullptr);
+                if (l == 0)
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
+                                       (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[0], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
+                                       c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                else
+                    hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, gz), block, 2 * 16 * S.P * sizeof(T), st, S,
+                                       c.G[gi], blk(s->i_wsh[l]), Kh, c.ZB, Nout, S.P);
             }
             {
                 // ... then the N electron tiles with the fused epilogue
@@ -351,44 +356,34 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 if (res)
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N, (unsigned)Bc, gz), block, 0, st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
-                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]));
+                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
                 else
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N, (unsigned)Bc, gz), block, 0, st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
-                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]));
-            }
-            if (l + 1 < S.n_layers) {
-                ProfScope ps(s, DS_PROF_LAYER_EPILOGUE, st);
-                hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)(((size_t)Nout * S.P + 255) / 256), S.nch, (unsigned)Bc),
-                                   dim3(256), 0, st, S, c.G[gi ^ 1], c.MEAN[mi ^ 1], Nout, S.P);
+                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
             }
         });
         if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
-        gi ^= 1; mi ^= 1;
+        gi ^= 1;
         if (l < S.n_double) {
             hi ^= 1;
             if (stop == STOP_H2_1 + l) return copy_out(dr, c.H2[hi], (size_t)S.h2[l + 1] * 5 * S.NP * Bc, st);
         }
-        if (stop == STOP_MEAN1 && l == 0) return copy_out(dr, c.MEAN[mi], (size_t)S.nch * Nout * S.P * Bc, st);
     }
     if (stop == STOP_G0 + S.n_layers) return copy_out(dr, c.G[gi], L.G * Bc, st);
-    // orbitals: GEMM over the electrons of one spin, then envelope/phase product rule
+    // orbitals: GEMM over the electrons of one spin with the envelope/phase product rule fused in
     for (int sp = 0; sp < S.nch; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp], Kh = S.h1[S.n_layers];
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
-            {
-                ProfScope ps(s, DS_PROF_ORBITAL, st);
-                dim3 block; unsigned gz;
-                gemm_geom(OC, NB, &block, &gz);
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(ns, (unsigned)Bc, gz), block, 0, st,
-                                   c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
-                                   blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, c.ZB,
-                                   (size_t)ns * OC * S.P, OC, S.P, (const T*)nullptr, (const T*)nullptr);
-            }
-            ProfScope ps(s, DS_PROF_ORBITAL_EPILOGUE, st);
-            hipLaunchKernelGGL((ds::k_orbital_epilogue<T, ST>), dim3(ns, (unsigned)Bc), dim3(256), 0, st, S, c.ZB,
-                               (size_t)ns * OC * S.P, c.Q, c.MOUT, sp, L.MOUT, L.mout_off[sp]);
+            ProfScope ps(s, DS_PROF_ORBITAL, st);
+            dim3 block; unsigned gz;
+            gemm_geom(OC, NB, &block, &gz);
+            ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[sp], S.N, i0, ns, S.nparam[sp], S.nparam_max};
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 5>), dim3(ns, (unsigned)Bc, gz), block, 0, st,
+                               c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
+                               blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
+                               (size_t)0, OC, S.P, (const T*)nullptr, (const T*)nullptr, oe);
         });
         if (rc) return fail("no orbital kernel instance for %d slot tiles", S.P / 16);
     }
@@ -407,8 +402,10 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         ProfScope ps(s, DS_PROF_DET_TRACE, st);
 #define DS_TRACE(NMAX, SP)                                                                                                    \
     do {                                                                                                                      \
-        size_t sh = ((size_t)n * n + (size_t)SP * n * n + 256) * sizeof(ds::Cx<T>);                                             \
-        hipLaunchKernelGGL((ds::k_det_trace<T, NMAX, SP>), dim3(S.K, (unsigned)Bc), dim3(256), sh, st, S, c.MOUT, L.MOUT,      \
+        const int rp = ((n * SP + 63) / 64 * 64) / SP;            /* rows per pass: whole waves, >= n when it fits */        \
+        const int nthr = std::min(256, rp * SP);                                                                               \
+        size_t sh = ((size_t)n * n + (size_t)SP * (n * n + 1) + nthr) * sizeof(ds::Cx<T>);                                            \
+        hipLaunchKernelGGL((ds::k_det_trace<T, NMAX, SP>), dim3(S.K, (unsigned)Bc), dim3(nthr), sh, st, S, c.MOUT, L.MOUT,     \
                            L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,        \
                            L.dets_off[sp]);                                                                                    \
     } while (0)
@@ -469,19 +466,20 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void*
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
         dim3 block; unsigned gz;
         gemm_geom(Nout, 4, &block, &gz);
-        hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
-                           (const T*)nullptr, 0, MEAN[mi], (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
-                           (const T*)nullptr, (const T*)nullptr);
+        if (l == 0)
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
+                               (const T*)nullptr, 0, MEAN[0], (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
+                               (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+        else
+            hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, gz), block, 2 * 16 * PV * sizeof(T), st, S, G[gi],
+                               blk(s->i_wsh[l]), Kh, ZB, Nout, PV);
         if (Kh == Nout)
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, 0, st, G[gi], gws, gts, blk(s->i_wloc[l]), Kloc,
-                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, G[gi ^ 1], (size_t)0, Nout, PV, ZB, blk(s->i_b[l]));
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, G[gi ^ 1], (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
         else
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 3>), dim3(S.N, (unsigned)ng, gz), block, 0, st, G[gi], gws, gts, blk(s->i_wloc[l]), Kloc,
-                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, G[gi ^ 1], (size_t)0, Nout, PV, ZB, blk(s->i_b[l]));
-        if (l + 1 < S.n_layers)
-            hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)(((size_t)Nout * PV + 255) / 256), S.nch, (unsigned)ng), dim3(256), 0, st,
-                               S, G[gi ^ 1], MEAN[mi ^ 1], Nout, PV);
-        gi ^= 1; mi ^= 1;
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, G[gi ^ 1], (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+        gi ^= 1;
         if (l < S.n_double) hi ^= 1;
     }
     for (int sp = 0; sp < S.nch; ++sp) {
@@ -490,7 +488,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void*
         gemm_geom(OC, 4, &oblock, &ogz);
         hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, G[gi] + (size_t)i0 * S.ldk * PV,
                            gws, gts, blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, ZB, (size_t)ns * OC * PV,
-                           OC, PV, (const T*)nullptr, (const T*)nullptr);
+                           OC, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
         hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, ZB, (size_t)ns * OC * PV, Q, MOUT, sp,
                            L.MOUT, L.mout_off[sp]);
     }

@@ -1,9 +1,10 @@
 // ds_gemm.h -- the dense contraction of the chain and its element-wise epilogues.
 //
 //   k_jet_gemm          Z[tile][n][slot] = sum_k W[k][n] * X[tile][k][slot]      (fp64/fp32 MFMA)
-//                       with an optional fused one-electron-layer epilogue (tanh chain rule, residual)
+//                       with optional fused epilogues: one-electron layer (tanh chain rule, residual)
+//                       or orbital head (envelope x phase product rule)
 //   k_spin_mean         spin means of the new one-electron stream
-//   k_orbital_epilogue  M = (Re,Im)(Phi) * q  with the product rule on the jets
+//   k_shared_term       the per-walker spin-mean term of a hidden layer, means formed on the fly
 //
 // The GEMM main loop needs only its accumulators and two k-steps of operands in registers, which
 // keeps two waves per SIMD resident: one wave's loads / epilogue hide behind the other's MFMAs.
@@ -11,6 +12,22 @@
 #include "ds_kernels.h"
 
 namespace ds {
+
+// Orbital-head weights are packed so that the MFMA accumulator hands one lane the pairs (Re, Im) of
+// two orbitals: in every 16-column tile t, lane group q = lane >> 4 owns accumulator registers
+// r = 0..3 = (Re p, Im p, Re p', Im p') with p = 8t + q, p' = p + 4.  Column of (p, part):
+template <typename T> __device__ __forceinline__ int orb_col(int p, int part) {
+    const int t = p >> 3, q = p & 3, r = 2 * ((p >> 2) & 1) + part;
+    return 16 * t + acc_row<T>(q << 4, r);
+}
+
+// fused orbital epilogue arguments (EPI = 5): M = phi * q with the product rule on the jets
+template <typename T> struct OrbEpi {
+    const T* Q;            // [walker][electron][nparam_max][10]
+    T* MOUT;               // [walker][spin][det][elec][orb][re,im][P]
+    size_t mout_stride, mout_off;
+    int N, i0, ns, nparam, nparam_max;
+};
 
 // One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x up to 1024/NB
 // output features (grid.z walks further column blocks); every wave owns 16*NB features.  Tiles 0..n_tiles-1 use (X, W, K);
@@ -21,12 +38,14 @@ namespace ds {
 //              the jets, (EPI = 2) residual with the layer input rows, store into the next layer's G.
 //              S : [walker][Nout][P] shared spin-mean term, Gout : [walker][tile][ldo rows][P].
 //   EPI = 3/4: value chain (slots = walkers): plain tanh(Z + S + b) without / with residual.
+//   EPI = 5: orbital head (network.py:543-557): complex phi from packed columns, M = phi * q (envelope x Bloch
+//            phase 5-jet of the tile's electron) with the product rule, stored into MOUT.
 template <typename T, int NB, int ST, int EPI>
 __global__ void __launch_bounds__(1024 / NB, (NB == 4 ? 2 : 1))
 k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride, const T* __restrict__ W, int K,
            const T* __restrict__ X2, size_t x2_walker_stride, const T* __restrict__ W2, int K2, int n_tiles,
            T* __restrict__ Z, size_t z_walker_stride, int Nout, int P, const T* __restrict__ Sb,
-           const T* __restrict__ bias) {
+           const T* __restrict__ bias, OrbEpi<T> oe) {
     typedef typename Acc4<T>::type acc_t;
     const int tile = blockIdx.x, w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4, n0 = (blockIdx.z * (blockDim.x >> 6) + wave) * 16 * NB;
@@ -99,6 +118,51 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 #pragma unroll
                 for (int s = 0; s < ST; ++s) Zp[(size_t)n * P + 16 * s + lr] = acc[a][s][r];
             }
+    } else if (EPI == 5) {
+        const int i = oe.i0 + tile, so = 2 + 3 * i, base = lane & 48;
+        T* Mw = oe.MOUT + (size_t)w * oe.mout_stride + oe.mout_off;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int ab = 0; ab < 2; ++ab) {
+                const int p = 8 * (n0 / 16 + a) + lq + 4 * ab;
+                const bool valid = p < oe.nparam;
+                const T* q = oe.Q + ((size_t)(w * oe.N + i) * oe.nparam_max + (valid ? p : 0)) * 10;
+                const Cx<T> qv(q[0], q[1]), qg0(q[2], q[3]), qg1(q[4], q[5]), qg2(q[6], q[7]), ql(q[8], q[9]);
+                Cx<T> phi[ST];
+#pragma unroll
+                for (int s = 0; s < ST; ++s) phi[s] = Cx<T>(acc[a][s][2 * ab], acc[a][s][2 * ab + 1]);
+                const Cx<T> f0(__shfl(phi[0].re, base), __shfl(phi[0].im, base));
+                const Cx<T> fL(__shfl(phi[0].re, base | 1), __shfl(phi[0].im, base | 1));
+                Cx<T> fo[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int sl = so + c, st = sl >> 4, src = base | (sl & 15);
+                    T re = 0, im = 0;
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) {
+                        const T tr = __shfl(phi[s].re, src), ti = __shfl(phi[s].im, src);
+                        if (s == st) { re = tr; im = ti; }
+                    }
+                    fo[c] = Cx<T>(re, im);
+                }
+                const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
+                if (valid) {
+                    const int kdet = p / oe.ns, m = p % oe.ns;
+                    T* mo = Mw + (((size_t)(kdet * oe.ns + tile) * oe.ns + m) * 2) * P + lr;
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) {
+                        const int slot = 16 * s + lr;
+                        Cx<T> v = phi[s] * qv;
+                        if (slot == 1) v = lap;
+                        else if (slot == so) v = v + f0 * qg0;
+                        else if (slot == so + 1) v = v + f0 * qg1;
+                        else if (slot == so + 2) v = v + f0 * qg2;
+                        mo[16 * s] = v.re;
+                        mo[P + 16 * s] = v.im;
+                    }
+                }
+            }
     } else {
         // Z here is the next layer's G: [walker][tile][x_tile_stride / P rows][P] (same geometry as X)
         const T rs2 = T(0.70710678118654752440);
@@ -149,6 +213,73 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     }
 }
 
+// Shared spin-mean term of a hidden layer, S[n][slot] = sum_sp sum_k W_sh[sp*Kh + k][n] * mean_{i in sp} G[i][k][slot]
+// (network.py:327-330: the tiled spin means of h_one), with the means formed on the fly:
+// a workgroup (one walker, NW waves of 16*NB features) sums the n_s electron rows of a 16-row K chunk into
+// LDS (each thread owns KC*P/threads elements, fully coalesced), then every wave runs 4 k-steps on it.
+template <typename T, int NB, int ST>
+__global__ void __launch_bounds__(1024 / NB, (NB == 4 ? 2 : 1))
+k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, int Kh, T* __restrict__ Sb, int Nout, int P) {
+    typedef typename Acc4<T>::type acc_t;
+    constexpr int KC = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* mbuf = reinterpret_cast<T*>(smem_raw);            // [2][KC][P]
+    const int w = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lq = lane >> 4, n0 = (blockIdx.z * (nthr >> 6) + wave) * 16 * NB;
+    const bool active = n0 < Nout;                        // inactive waves still help with the means
+    const T* Gw = G + (size_t)w * S.N * S.ldk * P;
+    const int nchunk = S.nch * Kh / KC;                   // Kh is a multiple of 64
+    acc_t acc[NB][ST];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int s = 0; s < ST; ++s) acc[a][s] = acc_t{0, 0, 0, 0};
+    auto fill = [&](int c, T* dst) {
+        const int sp = (c * KC) / Kh, k0 = (c * KC) % Kh;
+        const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn;
+        const T inv = T(1) / T(ns);
+        const T* g0 = Gw + ((size_t)i0 * S.ldk + k0) * P;
+        for (int e = tid; e < KC * P; e += nthr) {
+            T v = 0;
+#pragma unroll 4
+            for (int i = 0; i < ns; ++i) v += g0[(size_t)i * S.ldk * P + e];
+            dst[e] = v * inv;
+        }
+    };
+    fill(0, mbuf);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const T* cur = mbuf + (c & 1) * KC * P;
+        if (c + 1 < nchunk) fill(c + 1, mbuf + ((c + 1) & 1) * KC * P);
+        if (active) {
+            const T* Wp = Wsh + (size_t)(c * KC + lq) * Nout + n0 + lr;
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ++ks) {
+                T av[NB], bv[ST];
+#pragma unroll
+                for (int a = 0; a < NB; ++a) av[a] = Wp[(size_t)(4 * ks) * Nout + 16 * a];
+#pragma unroll
+                for (int s = 0; s < ST; ++s) bv[s] = cur[(4 * ks + lq) * P + 16 * s + lr];
+#pragma unroll
+                for (int a = 0; a < NB; ++a)
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[a], bv[s], acc[a][s]);
+            }
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    T* Sp = Sb + (size_t)w * Nout * P;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 16 * a + acc_row<T>(lane, r);
+#pragma unroll
+            for (int s = 0; s < ST; ++s) Sp[(size_t)n * P + 16 * s + lr] = acc[a][s][r];
+        }
+}
+
 // spin means of the new one-electron stream:  MEAN[w][sp][n][slot] = mean_{i in sp} G[w][i][n][slot]
 template <typename T>
 __global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restrict__ G, T* __restrict__ MEANout, int Nout, int P) {
@@ -161,63 +292,6 @@ __global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restr
 #pragma unroll 4
     for (int i = 0; i < ns; ++i) acc += g[(size_t)i * S.ldk * P];
     MEANout[(((size_t)w * S.nch + sp) * Nout) * P + e] = acc / T(ns);
-}
-
-// Orbital head epilogue (network.py:543-557): complex phi = (Phi[p], Phi[nparam + p]),
-// M = phi * q with q = envelope * Bloch phase (a 5-jet in the electron's own coordinates).
-//   Phi  : [walker][electron in spin][ocols][P]  (the GEMM output, natural column order)
-//   MOUT : [walker][spin][det][elec][orb][re/im][P]
-template <typename T, int ST>
-__global__ void __launch_bounds__(256) k_orbital_epilogue(SysDev<T> S, const T* __restrict__ PHI, size_t phi_walker_stride,
-                                                          const T* __restrict__ Q, T* __restrict__ MOUT, int sp,
-                                                          size_t mout_stride, size_t mout_off) {
-    const int ii = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, lr = tid & 15, g = tid >> 4;
-    const int lane = tid & 63, base = lane & 48;
-    const int N = S.N, P = S.P, OC = S.ocols[sp];
-    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn, nparam = S.nparam[sp];
-    const int i = i0 + ii, so = 2 + 3 * i;
-    const T* Pw = PHI + (size_t)w * phi_walker_stride + (size_t)ii * OC * P + lr;
-    T* Mw = MOUT + (size_t)w * mout_stride + mout_off;
-    for (int p0 = 0; p0 < nparam; p0 += 16) {
-        const int p = p0 + g;
-        const bool valid = p < nparam;
-        const int pc = valid ? p : 0;
-        const T* q = Q + ((size_t)(w * N + i) * S.nparam_max + pc) * 10;
-        const Cx<T> qv(q[0], q[1]), qg0(q[2], q[3]), qg1(q[4], q[5]), qg2(q[6], q[7]), ql(q[8], q[9]);
-        Cx<T> phi[ST];
-#pragma unroll
-        for (int s = 0; s < ST; ++s)
-            phi[s] = Cx<T>(Pw[(size_t)pc * P + 16 * s], Pw[(size_t)(nparam + pc) * P + 16 * s]);
-        const Cx<T> f0(__shfl(phi[0].re, base), __shfl(phi[0].im, base));
-        const Cx<T> fL(__shfl(phi[0].re, base | 1), __shfl(phi[0].im, base | 1));
-        Cx<T> fo[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int sl = so + c, st = sl >> 4, src = base | (sl & 15);
-            T re = 0, im = 0;
-#pragma unroll
-            for (int s = 0; s < ST; ++s) {
-                const T tr = __shfl(phi[s].re, src), ti = __shfl(phi[s].im, src);
-                if (s == st) { re = tr; im = ti; }
-            }
-            fo[c] = Cx<T>(re, im);
-        }
-        const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
-        if (!valid) continue;
-        const int kdet = p / ns, m = p % ns;
-        T* mo = Mw + (((size_t)(kdet * ns + ii) * ns + m) * 2) * P + lr;
-#pragma unroll
-        for (int s = 0; s < ST; ++s) {
-            const int slot = 16 * s + lr;
-            Cx<T> v = phi[s] * qv;
-            if (slot == 1) v = lap;
-            else if (slot == so) v = v + f0 * qg0;
-            else if (slot == so + 1) v = v + f0 * qg1;
-            else if (slot == so + 2) v = v + f0 * qg2;
-            mo[16 * s] = v.re;
-            mo[P + 16 * s] = v.im;
-        }
-    }
 }
 
 }  // namespace ds

@@ -338,38 +338,45 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
                                                    int sp, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                    T* __restrict__ TR, size_t tr_stride, size_t tr_off,
                                                    T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+    // blockDim.x = SP * RP with RP = rows per pass (n rounded up so that the block is whole waves):
+    // thread (dl, il) owns slot d0 + dl and matrix row ib + il.
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int RP = 256 / SP;
-    const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, RP = nthr / SP;
     const int P = S.P, n = sp == 0 ? S.n_up : S.n_dn;
     Cx<T>* minv = reinterpret_cast<Cx<T>*>(smem_raw);   // [n][n]
-    Cx<T>* ybuf = minv + n * n;                          // [SP slots][n][n]
-    Cx<T>* red = ybuf + SP * n * n;                      // [256]
+    Cx<T>* ybuf = minv + n * n;                          // [SP slots][n*n + 1]: +1 complex spreads the slots over the LDS banks
+    const int ys = n * n + 1;
+    Cx<T>* red = ybuf + SP * ys;                         // [nthr]
     const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
-    for (int idx = tid; idx < n * n; idx += 256) minv[idx] = Cx<T>(Iw[2 * idx], Iw[2 * idx + 1]);
+    for (int idx = tid; idx < n * n; idx += nthr) minv[idx] = Cx<T>(Iw[2 * idx], Iw[2 * idx + 1]);
     __syncthreads();
     const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
     T* Tw = TR + (size_t)w * tr_stride + tr_off + (size_t)kdet * 2 * P;
     const int dl = tid % SP, il = tid / SP;
     Cx<T> y2(0, 0);
-    for (int d0 = 0; d0 < P; d0 += SP) {
+    // slot 0 (the value: Y = 1) and the zero padding beyond D are skipped: start at slot 1
+    for (int d0 = 1; d0 < S.D; d0 += SP) {
         const int d = d0 + dl;
+        const bool live = d < S.D;
         for (int ib = 0; ib < n; ib += RP) {
             const int i = ib + il;
             if (i < n) {
                 Cx<T> yv[NMAX];
 #pragma unroll
                 for (int e = 0; e < NMAX; ++e) yv[e] = Cx<T>(0, 0);
-                for (int m = 0; m < n; ++m) {
-                    const T* mp = Mw + (size_t)((i * n + m) * 2) * P + d;
-                    const Cx<T> dm(mp[0], mp[P]);
+                if (live) {
+                    const T* mp = Mw + (size_t)(i * n * 2) * P + d;
+#pragma unroll 4
+                    for (int m = 0; m < n; ++m) {
+                        const Cx<T> dm(mp[(size_t)(2 * m) * P], mp[(size_t)(2 * m + 1) * P]);
 #pragma unroll
-                    for (int e = 0; e < NMAX; ++e)
-                        if (e < n) yv[e] = cx_fma(dm, minv[m * n + e], yv[e]);
+                        for (int e = 0; e < NMAX; ++e)
+                            if (e < n) yv[e] = cx_fma(dm, minv[m * n + e], yv[e]);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < NMAX; ++e)
-                    if (e < n) ybuf[(dl * n + i) * n + e] = yv[e];
+                    if (e < n) ybuf[dl * ys + i * n + e] = yv[e];
             }
         }
         __syncthreads();
@@ -377,15 +384,15 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
         for (int ib = 0; ib < n; ib += RP) {
             const int i = ib + il;
             if (i < n) {
-                trc = trc + ybuf[(dl * n + i) * n + i];
+                trc = trc + ybuf[dl * ys + i * n + i];
                 if (d >= 2)
-                    for (int e = 0; e < n; ++e) y2 = cx_fma(ybuf[(dl * n + i) * n + e], ybuf[(dl * n + e) * n + i], y2);
+                    for (int e = 0; e < n; ++e) y2 = cx_fma(ybuf[dl * ys + i * n + e], ybuf[dl * ys + e * n + i], y2);
             }
         }
         // reduce the trace over the row-groups holding the same slot
         red[tid] = trc;
         __syncthreads();
-        if (il == 0) {
+        if (il == 0 && live) {
             Cx<T> t(0, 0);
             for (int g = 0; g < RP; ++g) t = t + red[g * SP + dl];
             Tw[d] = t.re;
@@ -395,14 +402,12 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
     }
     red[tid] = y2;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] = red[tid] + red[tid + off];
-        __syncthreads();
-    }
     if (tid == 0) {
+        Cx<T> t(0, 0);
+        for (int g = 0; g < nthr; ++g) t = t + red[g];
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
-        dw[2] = red[0].re;
-        dw[3] = red[0].im;
+        dw[2] = t.re;
+        dw[3] = t.im;
     }
 }
 

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_orbital_epilogue_val(SysDev<T> S, const
     T* Mw = MOUT + (size_t)g * mout_stride + mout_off;
     for (int idx = threadIdx.x; idx < nparam * PV; idx += blockDim.x) {
         const int c = idx % PV, p = idx / PV;
-        const Cx<T> phi(Pw[(size_t)p * PV + c], Pw[(size_t)(nparam + p) * PV + c]);
+        const Cx<T> phi(Pw[(size_t)orb_col<T>(p, 0) * PV + c], Pw[(size_t)orb_col<T>(p, 1) * PV + c]);
         const Cx<T> q(Qw[(size_t)(p * 2) * PV + c], Qw[(size_t)(p * 2 + 1) * PV + c]);
         const Cx<T> v = phi * q;
         T* mo = Mw + (((size_t)((p / ns) * ns + ii) * ns + p % ns) * 2) * PV + c;

@@ -228,10 +228,19 @@ class DeviceSystem:
         return flat
 
     def _orbital_column_map(self, nparam, cols):
-        """Packed column c -> reference column of orbital[s]['w'] (or -1 for the zero padding that
-        rounds 2*nparam up to a multiple of 64): natural order, Re columns then Im columns."""
+        """Packed column c -> reference column of orbital[s]['w'] (or -1 for zero padding).
+        Within every 16-column tile t the MFMA accumulator gives lane group q = lane >> 4 the rows
+        {q, q+4, q+8, q+12} (f64) or {4q .. 4q+3} (f32) in registers r = 0..3; they are assigned
+        (Re p, Im p, Re p+4, Im p+4) with p = 8t + q, so the complex product with the envelope/phase jet
+        is lane-local in the fused orbital epilogue (csrc/ds_gemm.h: orb_col)."""
         src = -np.ones(cols, dtype=np.int64)
-        src[:2 * nparam] = np.arange(2 * nparam)
+        for t in range(cols // 16):
+            for q in range(4):
+                for r in range(4):
+                    row = q + 4 * r if self.dtype == torch.float64 else 4 * q + r
+                    p = 8 * t + q + 4 * (r // 2)
+                    if p < nparam:
+                        src[16 * t + row] = p + (r % 2) * nparam
         return src
 
     # ------------------------------------------------------------------ calls
