@@ -37,6 +37,27 @@ def layer_flops(n_elec, kloc, nout):
     return 2.0 * n_elec * d * kloc * nout
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes, calibrated against a copy of
+    known size -- on gfx950 raw FETCH_SIZE is half the bytes, see profiles/*_pmc_traffic.json).
+    bench.py cannot run rocprofv3 around itself, so this is the value measured for the same kernel,
+    system and 1024-walker launch size when the profile was taken; None if no profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            d = json.load(open(f))
+            for name, e in d['kernels'].items():
+                if name.startswith(kernel_prefix) and 'read_bytes_per_launch' in e and 'write_bytes_per_launch' in e:
+                    best = dict(bytes_per_launch=e['read_bytes_per_launch'] + e['write_bytes_per_launch'],
+                                read=e['read_bytes_per_launch'], write=e['write_bytes_per_launch'],
+                                walkers_per_launch=d.get('walkers_per_launch'), source=os.path.basename(f))
+        except Exception:
+            pass
+    return best
+
+
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
@@ -159,10 +180,16 @@ def main():
         'energy_mean_ha': float(loss), 'energy_imag_ha': float(aux.imaginary), 'variance': float(aux.variance),
         'roofline': {'bound': 'mfma', 'kernel': 'k_jet_gemm<%s,4,5,2> (hidden one-electron layers: K=%d MFMA GEMM + fused tanh-jet epilogue)' % ('double' if dtype == torch.float64 else 'float', h1 + nch * h2),
                      'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                     'traffic': None, 'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch,
+                     'traffic': None, 'traffic_detail': None, 'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch,
                      'flops_per_walker_layer': f_layer},
         'kernel_ms_per_step': {k: v[0] / args.steps for k, v in prof.items()},
     }
+    if args.system == 'bcc_li' and dtype == torch.float64:
+        tr = pmc_traffic('ds::k_jet_gemm<double, 4, 5, 2>')
+        if tr:
+            out['roofline']['traffic'] = tr['bytes_per_launch']
+            tr['algorithmic_bytes_per_launch'] = 8.0 * n_e * (3 * n_e + 2 + 15) // 16 * 16 * 0 + 8.0 * 1024 * n_e * 80 * ((h1 + nch * h2) + h1)
+            out['roofline']['traffic_detail'] = tr
     if world == 1 and not args.no_cpu_baseline:
         params_np = {k: [{kk: vv.cpu().numpy() for kk, vv in d.items()} for d in v] for k, v in params.items()}
         cb, err = cpu_baseline(cell, klist, net_kw, params_np, x_np, aux.local_energy[:8].cpu().numpy(), args.cpu_seconds)

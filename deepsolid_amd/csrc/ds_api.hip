@@ -799,6 +799,13 @@ int ds_profile_read(ds_system* s, double* ms_total, int64_t* launches) {
     return 0;
 }
 
+int ds_calib_copy(const void* src, void* dst, int64_t n_elems, void* stream) {
+    if (!src || !dst) return fail("null argument");
+    hipLaunchKernelGGL(ds::k_calib_copy, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const double*)src, (double*)dst, (size_t)n_elems);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int64_t ds_mfma_f64_peak(int64_t iters, int blocks_per_cu, int n_acc, void* scratch, void* stream) {
     const int blocks = 256 * blocks_per_cu;   // 4-wave blocks: blocks_per_cu waves per SIMD
     hipStream_t st = (hipStream_t)stream;

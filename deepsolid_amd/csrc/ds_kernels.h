@@ -611,6 +611,11 @@ __global__ void k_gather_slot0(const T* __restrict__ MOUT, size_t mout_stride, s
     if (idx < per) out[w * per + idx] = MOUT[w * mout_stride + mout_off + idx * P];
 }
 
+// HBM counter calibration: a plain 8-byte-per-lane copy (the access width of every jet tensor load / store)
+__global__ void k_calib_copy(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // fp64 MFMA issue-rate probe: NACC independent accumulators per wave
 template <int NACC>
 __global__ void __launch_bounds__(256) k_mfma_peak(long iters, double* out) {

@@ -177,6 +177,10 @@ int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_
 int ds_profile_enable(ds_system* sys, int on);
 int ds_profile_read(ds_system* sys, double* ms_total, int64_t* launches);
 
+/* Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters: copies n_elems float64
+ * with the 8-byte-per-lane access pattern of the jet tensors (known traffic = 8 n read + 8 n written). */
+int ds_calib_copy(const void* src, void* dst, int64_t n_elems, void* stream);
+
 /* fp64 MFMA issue-rate micro-benchmark used to confirm the roofline peak: every wave issues
  * `iters` x `n_acc` independent v_mfma_f64_16x16x4_f64 (n_acc = 1,2,4,8,16 accumulators), with
  * `blocks_per_cu` waves resident per SIMD; returns the FLOPs executed (caller times with HIP events). */

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh: per kernel, counter total
+per launch, calibrated against the copy kernel of known traffic (MI355X_MICROARCH.md: on gfx950 the
+raw FETCH_SIZE of a coalesced stream is not the byte count; calibrate in your own access pattern)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+CALIB_BYTES = 8 * (1 << 28)
+out = {'calib_bytes_each_way': CALIB_BYTES, 'walkers_per_launch': 1024, 'kernels': {}}
+raw = {}
+for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    files = glob.glob(os.path.join(root, counter, '**', '*counter_collection.csv'), recursive=True)
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get('Counter_Name') != counter:
+                continue
+            name = row['Kernel_Name'].split('(')[0].replace('void ', '')
+            tot[name] += float(row['Counter_Value'])
+            cnt[name] += 1
+    raw[counter] = {k: (tot[k], cnt[k]) for k in tot}
+    calib = [v for k, v in raw[counter].items() if 'k_calib_copy' in k]
+    out[counter + '_units_per_byte'] = (calib[0][0] / calib[0][1]) / CALIB_BYTES if calib else None
+for name in sorted(set(raw['FETCH_SIZE']) | set(raw['WRITE_SIZE'])):
+    if not name.startswith('ds::'):
+        continue
+    e = {}
+    for counter, key in (('FETCH_SIZE', 'read'), ('WRITE_SIZE', 'write')):
+        if name in raw[counter] and out[counter + '_units_per_byte']:
+            t, c = raw[counter][name]
+            e[key + '_bytes_per_launch'] = t / c / out[counter + '_units_per_byte']
+            e['launches'] = c
+    out['kernels'][name] = e
+print(json.dumps(out, indent=1))
