@@ -188,7 +188,9 @@ def main():
         tr = pmc_traffic('ds::k_jet_gemm<double, 4, 5, 2>')
         if tr:
             out['roofline']['traffic'] = tr['bytes_per_launch']
-            tr['algorithmic_bytes_per_launch'] = 8.0 * n_e * (3 * n_e + 2 + 15) // 16 * 16 * 0 + 8.0 * 1024 * n_e * 80 * ((h1 + nch * h2) + h1)
+            p_slots = (3 * n_e + 2 + 15) // 16 * 16
+            # read every layer-input row once, write every output row once (weights and S are L2-resident)
+            tr['algorithmic_bytes_per_launch'] = 8.0 * tr['walkers_per_launch'] * n_e * p_slots * ((h1 + nch * h2) + h1)
             out['roofline']['traffic_detail'] = tr
     if world == 1 and not args.no_cpu_baseline:
         params_np = {k: [{kk: vv.cpu().numpy() for kk, vv in d.items()} for d in v] for k, v in params.items()}

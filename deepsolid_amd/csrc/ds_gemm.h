@@ -47,7 +47,17 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
            T* __restrict__ Z, size_t z_walker_stride, int Nout, int P, const T* __restrict__ Sb,
            const T* __restrict__ bias, OrbEpi<T> oe) {
     typedef typename Acc4<T>::type acc_t;
-    const int tile = blockIdx.x, w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), so
+    // linear ids b, b+8, b+16, ... share an L2.  All tiles of one walker are given ids of one residue class:
+    // they then share that L2's copy of the walker's S term (and run back to back).  Pure speed, any
+    // placement gives the same result.
+    int tile = blockIdx.x, w = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, q = b >> 3;
+        w = (q / gridDim.x) * 8 + (b & 7);
+        tile = q % gridDim.x;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4, n0 = (blockIdx.z * (blockDim.x >> 6) + wave) * 16 * NB;
     if (n0 >= Nout) return;                      // column blocks beyond Nout (grid.z rounds up)
     const T* Xp;
