@@ -64,7 +64,7 @@ struct ds_system {
     WsLayout ws;                      // forward-Laplacian chain, per walker
     WsLayout wsv;                     // value chain, per group of PV walkers
     // block indices
-    std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_pi, i_sg;
+    std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_borb, i_pi, i_sg;
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[DS_PROF_KINDS];
@@ -117,7 +117,12 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
     size_t o_pav = push(d->prim_AV, 3 * d->n_sym), o_pbv = push(d->prim_BV, 3 * d->n_sym);
     size_t o_sav = push(d->sim_AV, 3 * d->n_sym), o_sbv = push(d->sim_BV, 3 * d->n_sym);
     size_t o_at = push(d->prim_atoms, 3 * d->n_atoms_prim);
-    size_t o_k0 = push(d->klist_up, 3 * d->n_up), o_k1 = d->n_dn ? push(d->klist_dn, 3 * d->n_dn) : o_k0;
+    // k-vector table per spin; with full_det every spin block sees the concatenated list (network.py:452-454)
+    std::vector<double> kcat(d->klist_up, d->klist_up + 3 * d->n_up);
+    if (d->n_dn) kcat.insert(kcat.end(), d->klist_dn, d->klist_dn + 3 * d->n_dn);
+    size_t o_k0, o_k1;
+    if (d->full_det) { o_k0 = o_k1 = push(kcat.data(), kcat.size()); }
+    else { o_k0 = push(d->klist_up, 3 * d->n_up); o_k1 = d->n_dn ? push(d->klist_dn, 3 * d->n_dn) : o_k0; }
     size_t o_sat = push(d->sim_atoms, 3 * d->n_atoms_sim), o_q = push(d->sim_charges, d->n_atoms_sim);
     size_t o_d27 = push(disp, 81), o_s27 = push(shift, 81);
     size_t o_g = push(d->gpoints, 3 * (size_t)d->n_g), o_gw = push(d->gweight, d->n_g);
@@ -141,7 +146,15 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
     }
     ldk = std::max(ldk, S.h1[d->n_layers]);
     S.ldk = ldk;
-    S.nparam[0] = d->n_up * d->n_det; S.nparam[1] = d->n_dn * d->n_det;
+    S.full_det = d->full_det; S.env_type = d->envelope_type; S.bias_orb = d->bias_orbitals;
+    if (d->full_det) {
+        S.norb[0] = S.norb[1] = S.N; S.n_detch = 1; S.det_n[0] = S.N; S.det_n[1] = 0;
+        S.mat_ch[0] = S.mat_ch[1] = 0; S.row_off[0] = 0; S.row_off[1] = d->n_up;
+    } else {
+        S.norb[0] = d->n_up; S.norb[1] = d->n_dn; S.n_detch = S.nch; S.det_n[0] = d->n_up; S.det_n[1] = d->n_dn;
+        S.mat_ch[0] = 0; S.mat_ch[1] = 1; S.row_off[0] = S.row_off[1] = 0;
+    }
+    S.nparam[0] = S.norb[0] * d->n_det; S.nparam[1] = d->n_dn ? S.norb[1] * d->n_det : 0;
     S.nparam_max = std::max(S.nparam[0], S.nparam[1]);
     S.ocols[0] = rup(2 * S.nparam[0], 64); S.ocols[1] = rup(2 * S.nparam[1], 64);
     S.As = d->n_atoms_sim; S.NG = d->n_g; S.dist_mode = d->dist_mode;
@@ -181,8 +194,10 @@ void build_layouts(ds_system* s) {
     }
     for (int c = 0; c < S.nch; ++c) {
         s->i_worb.push_back(add(S.h1[S.n_layers], S.ocols[c]));
+        s->i_borb.push_back(S.bias_orb ? add(1, 2 * S.nparam[c]) : -1);
         s->i_pi.push_back(add(S.A, S.nparam[c]));
-        s->i_sg.push_back(add(S.A, S.nparam[c]));
+        const int sig_rows = S.env_type == 0 ? S.A : (S.env_type == 1 ? 3 * S.A : 9 * S.A);   // network.py:146-152
+        s->i_sg.push_back(add(sig_rows, S.nparam[c]));
     }
     s->nparams = off;
     WsLayout& w = s->ws;
@@ -196,8 +211,8 @@ void build_layouts(ds_system* s) {
     w.H2 = (size_t)h2max * 5 * S.NP;
     w.Q = (size_t)S.N * S.nparam_max * 10;
     size_t mo = 0, mi = 0, de = 0, tr = 0;
-    for (int c = 0; c < 2; ++c) {
-        const size_t n = c == 0 ? S.n_up : S.n_dn;
+    for (int c = 0; c < 2; ++c) {                     // c = determinant channel
+        const size_t n = c < S.n_detch ? S.det_n[c] : 0;
         w.mout_off[c] = mo; w.minv_off[c] = mi; w.dets_off[c] = de; w.tr_off[c] = tr;
         mo += (size_t)S.K * n * n * 2 * S.P;
         mi += (size_t)S.K * n * n * 2;
@@ -218,7 +233,7 @@ void build_layouts(ds_system* s) {
     v.Q = (size_t)S.N * S.nparam_max * 2 * PV;
     mo = 0;
     for (int c = 0; c < 2; ++c) {
-        const size_t n = c == 0 ? S.n_up : S.n_dn;
+        const size_t n = c < S.n_detch ? S.det_n[c] : 0;
         v.mout_off[c] = mo;
         mo += (size_t)S.K * n * n * 2 * PV;
     }
@@ -379,7 +394,9 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             ProfScope ps(s, DS_PROF_ORBITAL, st);
             dim3 block; unsigned gz;
             gemm_geom(OC, NB, &block, &gz);
-            ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[sp], S.N, i0, ns, S.nparam[sp], S.nparam_max};
+            const int ch = S.mat_ch[sp];
+            ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
+                             S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr};
             hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 5>), dim3(ns, (unsigned)Bc, gz), block, 0, st,
                                c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
                                blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
@@ -389,16 +406,16 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     }
     if (stop == STOP_MOUT) return copy_out(dr, c.MOUT, L.MOUT * Bc, st);
     // determinants
-    for (int sp = 0; sp < S.nch; ++sp) {
-        const int n = sp == 0 ? S.n_up : S.n_dn;
+    for (int sp = 0; sp < S.n_detch; ++sp) {          // sp = determinant channel from here on
+        const int n = S.det_n[sp];
         size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
         ProfScope ps(s, DS_PROF_DET_INVERSE, st);
         hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp,
                            c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp], S.P, 1);
     }
     if (stop == STOP_MINV) return copy_out(dr, c.MINV, L.MINV * Bc, st);
-    for (int sp = 0; sp < S.nch; ++sp) {
-        const int n = sp == 0 ? S.n_up : S.n_dn;
+    for (int sp = 0; sp < S.n_detch; ++sp) {
+        const int n = S.det_n[sp];
         ProfScope ps(s, DS_PROF_DET_TRACE, st);
 #define DS_TRACE(NMAX, SP)                                                                                                    \
     do {                                                                                                                      \
@@ -490,13 +507,13 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void*
                            gws, gts, blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, ZB, (size_t)ns * OC * PV,
                            OC, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
         hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, ZB, (size_t)ns * OC * PV, Q, MOUT, sp,
-                           L.MOUT, L.mout_off[sp]);
+                           L.MOUT, L.mout_off[S.mat_ch[sp]], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr);
     }
     if (mout_ptr) *mout_ptr = MOUT;
     if (out_logabs || out_phase) {
         const size_t dstride = s->ws.DETS;
-        for (int sp = 0; sp < S.nch; ++sp) {
-            const int n = sp == 0 ? S.n_up : S.n_dn;
+        for (int sp = 0; sp < S.n_detch; ++sp) {
+            const int n = S.det_n[sp];
             size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
             hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, MOUT, L.MOUT, L.mout_off[sp], sp,
                                (T*)nullptr, (size_t)0, (size_t)0, DETS, dstride, s->ws.dets_off[sp], PV, PV);
@@ -536,8 +553,8 @@ int orbitals_impl(ds_system* s, const void* params, const void* x, int64_t B, vo
         T* mout = nullptr;
         int rc = run_value_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, ws, st, nullptr, nullptr, &mout);
         if (rc) return rc;
-        for (int sp = 0; sp < S.nch; ++sp) {
-            const int n = sp == 0 ? S.n_up : S.n_dn;
+        for (int sp = 0; sp < S.n_detch; ++sp) {
+            const int n = S.det_n[sp];
             T* o = (T*)(sp == 0 ? out_up : out_dn);
             if (!o) continue;
             const size_t per = (size_t)S.K * n * n * 2;
@@ -580,15 +597,16 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
 int check_arch(const ds_system_desc* d) {
     if (d->dtype != 0 && d->dtype != 1) return fail("dtype must be 0 (f64) or 1 (f32)");
     if (d->distance_type != 0) return fail("only distance_type='nu' is implemented on the device");
-    if (d->envelope_type != 0) return fail("only envelope_type='isotropic' is implemented on the device");
-    if (d->full_det) return fail("full_det=True is not implemented on the device");
+    if (d->envelope_type < 0 || d->envelope_type > 2) return fail("unknown envelope_type");
     if (d->use_last_layer) return fail("use_last_layer=True is not implemented on the device");
-    if (d->bias_orbitals) return fail("bias_orbitals=True is not implemented on the device");
     if (d->n_up < 1) return fail("n_up must be >= 1");
     if (d->n_dn > d->n_up) return fail("n_dn > n_up is not supported");
     if (d->n_layers < 1 || d->n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
     if (d->n_det < 1 || d->n_det > 32) return fail("n_det must be in 1..32");
-    if ((d->n_up * d->n_det) % 8 || (d->n_dn * d->n_det) % 8) return fail("n_s * n_det must be a multiple of 8");
+    {
+        const int no0 = d->full_det ? d->n_up + d->n_dn : d->n_up, no1 = d->full_det ? d->n_up + d->n_dn : d->n_dn;
+        if ((no0 * d->n_det) % 8 || (d->n_dn && (no1 * d->n_det) % 8)) return fail("orbitals per determinant x n_det must be a multiple of 8");
+    }
     if (d->n_sym < 3 || d->n_sym > DS_MAX_SYM) return fail("bad n_sym");
     return 0;
 }

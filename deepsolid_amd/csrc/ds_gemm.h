@@ -25,8 +25,10 @@ template <typename T> __device__ __forceinline__ int orb_col(int p, int part) {
 template <typename T> struct OrbEpi {
     const T* Q;            // [walker][electron][nparam_max][10]
     T* MOUT;               // [walker][spin][det][elec][orb][re,im][P]
-    size_t mout_stride, mout_off;
-    int N, i0, ns, nparam, nparam_max;
+    size_t mout_stride, mout_off;   // walker stride and offset of this spin's determinant channel
+    int N, i0, nparam, nparam_max;
+    int norb, n, row0;              // orbitals per det, matrix size, first matrix row of this spin's electrons
+    const T* bias;                  // optional orbital bias (2*nparam: Re then Im), value slot only; or null
 };
 
 // One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x up to 1024/NB
@@ -142,6 +144,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 Cx<T> phi[ST];
 #pragma unroll
                 for (int s = 0; s < ST; ++s) phi[s] = Cx<T>(acc[a][s][2 * ab], acc[a][s][2 * ab + 1]);
+                if (oe.bias && valid && lr == 0) { phi[0].re += oe.bias[p]; phi[0].im += oe.bias[oe.nparam + p]; }
                 const Cx<T> f0(__shfl(phi[0].re, base), __shfl(phi[0].im, base));
                 const Cx<T> fL(__shfl(phi[0].re, base | 1), __shfl(phi[0].im, base | 1));
                 Cx<T> fo[3];
@@ -158,8 +161,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 }
                 const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
                 if (valid) {
-                    const int kdet = p / oe.ns, m = p % oe.ns;
-                    T* mo = Mw + (((size_t)(kdet * oe.ns + tile) * oe.ns + m) * 2) * P + lr;
+                    const int kdet = p / oe.norb, m = p % oe.norb;
+                    T* mo = Mw + (((size_t)(kdet * oe.n + oe.row0 + tile) * oe.n + m) * 2) * P + lr;
 #pragma unroll
                     for (int s = 0; s < ST; ++s) {
                         const int slot = 16 * s + lr;

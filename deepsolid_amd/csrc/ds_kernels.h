@@ -29,11 +29,16 @@ template <typename T> struct SysDev {
     int h1[DS_MAXL + 1];          // h1[0] = 4A, h1[l+1] = hidden_single[l]
     int h2[DS_MAXL + 1];          // h2[0] = 4,  h2[l+1] = hidden_double[l]
     int ldk;                      // rows per electron in G
-    int nparam[2];                // n_s * K
+    int full_det, env_type, bias_orb;   // network options (network.py:609-621)
+    int norb[2];                  // orbitals per determinant seen by spin s: n_s, or N with full_det
+    int n_detch;                  // determinant channels: one per active spin, or 1 with full_det
+    int det_n[2];                 // matrix size of channel ch
+    int mat_ch[2], row_off[2];    // channel and first row that spin s's electrons fill
+    int nparam[2];                // norb * K
     int nparam_max;
     int ocols[2];                 // packed orbital columns (2*nparam rounded up to 64)
     const T *prim_a, *prim_ainv, *sim_a, *sim_ainv, *prim_AV, *prim_BV, *sim_AV, *sim_BV, *atoms;
-    const T* klist[2];
+    const T* klist[2];            // per spin: (norb[s], 3); with full_det both point to the concatenated list
     // Ewald
     int As, NG, dist_mode;
     const T *sim_atoms, *sim_charges, *disp27, *shift27, *gpoints, *gweight, *ion_re, *ion_im;
@@ -131,19 +136,36 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
     T* Qw = Q + (size_t)w * N * S.nparam_max * 10;
     for (int idx = tid; idx < N * S.nparam_max; idx += nt) {
         const int i = idx / S.nparam_max, p = idx % S.nparam_max;
-        const int s = spin_of(i, S.n_up), ns = s == 0 ? S.n_up : S.n_dn;
+        const int s = spin_of(i, S.n_up);
         if (p >= S.nparam[s]) continue;
         const T* pi_ = s == 0 ? env_pi0 : env_pi1;
         const T* sg_ = s == 0 ? env_sg0 : env_sg1;
+        const int np = S.nparam[s];
         Jet5<T> e = jet_zero<T>();
         for (int a = 0; a < A; ++a) {
-            const Jet5<T>& sd = jea[4 * (i * A + a)];
-            const T sg = sg_[a * S.nparam[s] + p], pw = pi_[a * S.nparam[s] + p];
-            const T u = sd.v * sg;
-            const T ex = pw * ds_exp(-ds_abs(u));
-            e = jet_add(e, jet_fn(sd, ex, -ds_sign(u) * sg * ex, sg * sg * ex));
+            const T pw = pi_[a * np + p];
+            if (S.env_type == 0) {            // isotropic (network.py:335-337): exp(-|sd sigma|)
+                const Jet5<T>& sd = jea[4 * (i * A + a)];
+                const T sg = sg_[a * np + p];
+                const T u = sd.v * sg;
+                const T ex = pw * ds_exp(-ds_abs(u));
+                e = jet_add(e, jet_fn(sd, ex, -ds_sign(u) * sg * ex, sg * sg * ex));
+            } else {                           // diagonal (:340-343) / full (:346-364): exp(-|Sigma rel|)
+                Jet5<T> r2 = jet_zero<T>();
+                for (int m = 0; m < 3; ++m) {
+                    Jet5<T> u = jet_zero<T>();
+                    if (S.env_type == 1) u = jet_scale(sg_[(a * 3 + m) * np + p], jea[4 * (i * A + a) + 1 + m]);
+                    else
+                        for (int k = 0; k < 3; ++k) u = jet_add(u, jet_scale(sg_[((k * 3 + m) * A + a) * np + p], jea[4 * (i * A + a) + 1 + k]));
+                    r2 = jet_add(r2, jet_mul(u, u));
+                }
+                const T r = ds_sqrt(r2.v);
+                const Jet5<T> rj = jet_fn(r2, r, T(0.5) / r, T(-0.25) / (r * r2.v));
+                const T ex = pw * ds_exp(-r);
+                e = jet_add(e, jet_fn(rj, ex, -ex, ex));
+            }
         }
-        const int m = p % ns;
+        const int m = p % S.norb[s];
         const T* kv = S.klist[s] + 3 * m;
         const T kx = kv[0] * xs[3 * i] + kv[1] * xs[3 * i + 1] + kv[2] * xs[3 * i + 2];
         T sn, cs;
@@ -262,7 +284,7 @@ __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __rest
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Cx<T>* aug = reinterpret_cast<Cx<T>*>(smem_raw);   // [n][2n]
     const int kdet = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
-    const int n = sp == 0 ? S.n_up : S.n_dn, n2 = 2 * n;
+    const int n = S.det_n[sp], n2 = 2 * n;      // sp = determinant channel
     int* piv_p = reinterpret_cast<int*>(aug + n * n2);  // all LDS in the one dynamic region (16-B aligned base)
     const T* Mw = MOUT + (size_t)(w / cols_per_group) * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P + w % cols_per_group;
     for (int idx = lane; idx < n * n; idx += 64) {
@@ -342,7 +364,7 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
     // thread (dl, il) owns slot d0 + dl and matrix row ib + il.
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, RP = nthr / SP;
-    const int P = S.P, n = sp == 0 ? S.n_up : S.n_dn;
+    const int P = S.P, n = S.det_n[sp];                  // sp = determinant channel
     Cx<T>* minv = reinterpret_cast<Cx<T>*>(smem_raw);   // [n][n]
     Cx<T>* ybuf = minv + n * n;                          // [SP slots][n*n + 1]: +1 complex spreads the slots over the LDS banks
     const int ys = n * n + 1;
@@ -429,7 +451,7 @@ __global__ void __launch_bounds__(64) k_combine(SysDev<T> S, const T* __restrict
     T mx = -1e300;
     for (int k = 0; k < K; ++k) {
         la[k] = Dw[4 * k]; ar[k] = Dw[4 * k + 1];
-        if (S.nch > 1) { la[k] += Dw[dets_off1 + 4 * k]; ar[k] += Dw[dets_off1 + 4 * k + 1]; }
+        if (S.n_detch > 1) { la[k] += Dw[dets_off1 + 4 * k]; ar[k] += Dw[dets_off1 + 4 * k + 1]; }
         mx = la[k] > mx ? la[k] : mx;
     }
     Cx<T> sum(0, 0);
@@ -448,12 +470,12 @@ __global__ void __launch_bounds__(64) k_combine(SysDev<T> S, const T* __restrict
         Cx<T> g2(0, 0);
         for (int d = 2 + lane; d < S.D; d += 64) {
             Cx<T> g(Tw[(size_t)(k * 2) * P + d], Tw[(size_t)(k * 2 + 1) * P + d]);
-            if (S.nch > 1) g = g + Cx<T>(Tw[tr_off1 + (size_t)(k * 2) * P + d], Tw[tr_off1 + (size_t)(k * 2 + 1) * P + d]);
+            if (S.n_detch > 1) g = g + Cx<T>(Tw[tr_off1 + (size_t)(k * 2) * P + d], Tw[tr_off1 + (size_t)(k * 2 + 1) * P + d]);
             g2 = g2 + g * g;
         }
         g2.re = wave_sum(g2.re); g2.im = wave_sum(g2.im);
         Cx<T> lap(Tw[(size_t)(k * 2) * P + 1] - Dw[4 * k + 2], Tw[(size_t)(k * 2 + 1) * P + 1] - Dw[4 * k + 3]);
-        if (S.nch > 1)
+        if (S.n_detch > 1)
             lap = lap + Cx<T>(Tw[tr_off1 + (size_t)(k * 2) * P + 1] - Dw[dets_off1 + 4 * k + 2],
                               Tw[tr_off1 + (size_t)(k * 2 + 1) * P + 1] - Dw[dets_off1 + 4 * k + 3]);
         ke = ke + (wk[k] * sinv) * (lap + g2);

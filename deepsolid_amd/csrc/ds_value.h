@@ -90,16 +90,29 @@ __global__ void __launch_bounds__(256) k_features_val(SysDev<T> S, const T* __re
     T* Qw = Q + (size_t)g * N * S.nparam_max * 2 * PV;
     for (int idx = tid; idx < N * S.nparam_max * PV; idx += nt) {
         const int c = idx % PV, p = (idx / PV) % S.nparam_max, i = idx / (PV * S.nparam_max);
-        const int s = spin_of(i, S.n_up), ns = s == 0 ? S.n_up : S.n_dn;
-        if (p >= S.nparam[s]) continue;
+        const int s = spin_of(i, S.n_up), np = S.nparam[s];
+        if (p >= np) continue;
         const T* pi_ = s == 0 ? env_pi0 : env_pi1;
         const T* sg_ = s == 0 ? env_sg0 : env_sg1;
         T e = 0;
         for (int a = 0; a < A; ++a) {
-            const T sd = Gw[((size_t)i * S.ldk + 4 * a) * PV + c];
-            e += pi_[a * S.nparam[s] + p] * ds_exp(-ds_abs(sd * sg_[a * S.nparam[s] + p]));
+            const T* f = Gw + ((size_t)i * S.ldk + 4 * a) * PV + c;     // rows sd, rel_x, rel_y, rel_z of atom a
+            T r;
+            if (S.env_type == 0) r = ds_abs(f[0] * sg_[a * np + p]);
+            else {
+                T r2 = 0;
+                for (int m = 0; m < 3; ++m) {
+                    T u = 0;
+                    if (S.env_type == 1) u = sg_[(a * 3 + m) * np + p] * f[(size_t)(1 + m) * PV];
+                    else
+                        for (int k = 0; k < 3; ++k) u += sg_[((k * 3 + m) * A + a) * np + p] * f[(size_t)(1 + k) * PV];
+                    r2 += u * u;
+                }
+                r = ds_sqrt(r2);
+            }
+            e += pi_[a * np + p] * ds_exp(-r);
         }
-        const T* kv = S.klist[s] + 3 * (p % ns);
+        const T* kv = S.klist[s] + 3 * (p % S.norb[s]);
         const T* xp = x + (size_t)walker(c) * 3 * N + 3 * i;
         T sn, cs;
         ds_sincos(kv[0] * xp[0] + kv[1] * xp[1] + kv[2] * xp[2], &sn, &cs);
@@ -127,18 +140,20 @@ __global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __r
 template <typename T>
 __global__ void __launch_bounds__(256) k_orbital_epilogue_val(SysDev<T> S, const T* __restrict__ PHI, size_t phi_group_stride,
                                                               const T* __restrict__ Q, T* __restrict__ MOUT, int sp,
-                                                              size_t mout_stride, size_t mout_off) {
+                                                              size_t mout_stride, size_t mout_off, const T* __restrict__ bias) {
     const int ii = blockIdx.x, g = blockIdx.y, N = S.N, OC = S.ocols[sp];
-    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn, nparam = S.nparam[sp], i = i0 + ii;
+    const int i0 = sp == 0 ? 0 : S.n_up, nparam = S.nparam[sp], i = i0 + ii;
+    const int norb = S.norb[sp], n = S.det_n[S.mat_ch[sp]], row = S.row_off[sp] + ii;
     const T* Pw = PHI + (size_t)g * phi_group_stride + (size_t)ii * OC * PV;
     const T* Qw = Q + ((size_t)(g * N + i) * S.nparam_max) * 2 * PV;
     T* Mw = MOUT + (size_t)g * mout_stride + mout_off;
     for (int idx = threadIdx.x; idx < nparam * PV; idx += blockDim.x) {
         const int c = idx % PV, p = idx / PV;
-        const Cx<T> phi(Pw[(size_t)orb_col<T>(p, 0) * PV + c], Pw[(size_t)orb_col<T>(p, 1) * PV + c]);
+        Cx<T> phi(Pw[(size_t)orb_col<T>(p, 0) * PV + c], Pw[(size_t)orb_col<T>(p, 1) * PV + c]);
+        if (bias) { phi.re += bias[p]; phi.im += bias[nparam + p]; }
         const Cx<T> q(Qw[(size_t)(p * 2) * PV + c], Qw[(size_t)(p * 2 + 1) * PV + c]);
         const Cx<T> v = phi * q;
-        T* mo = Mw + (((size_t)((p / ns) * ns + ii) * ns + p % ns) * 2) * PV + c;
+        T* mo = Mw + (((size_t)((p / norb) * n + row) * n + p % norb) * 2) * PV + c;
         mo[0] = v.re;
         mo[PV] = v.im;
     }

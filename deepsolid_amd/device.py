@@ -211,19 +211,25 @@ class DeviceSystem:
         for l in range(len(self.hidden_dims) - 1):
             put(dev(params['double'][l]['w']))
             put(dev(params['double'][l]['b']))
+        full_det = bool(self.net_kw.get('full_det', False))
         for c in range(nch):
-            ns = self.nelec[c]
-            nparam = ns * self.n_det
+            norb = self.n if full_det else self.nelec[c]
+            nparam = norb * self.n_det
             w = dev(params['orbital'][c]['w'])
-            off, rows, cols = self.blocks[3 * len(self.hidden_dims) + 2 * (len(self.hidden_dims) - 1) + 3 * c]
+            if w.shape[1] != 2 * nparam:
+                raise ValueError(f"orbital[{c}]['w'] has {w.shape[1]} columns, expected {2 * nparam}")
+            off, rows, cols = next(bi)
             src = self._orbital_column_map(nparam, cols)
             packed = torch.zeros(rows, cols, dtype=self.dtype, device=self.device)
             valid = src >= 0
             packed[:, torch.as_tensor(np.nonzero(valid)[0], device=self.device)] = \
                 w[:, torch.as_tensor(src[valid], device=self.device)]
-            put(packed)
+            flat[off:off + rows * cols] = packed.reshape(-1)
+            if self.net_kw.get('bias_orbitals', False):
+                put(dev(params['orbital'][c]['b']))
             put(dev(params['envelope'][c]['pi']))
-            put(dev(params['envelope'][c]['sigma']))
+            # sigma: (A, P) isotropic | (A, 3, P) diagonal -> rows a*3+c | (3, 3, A, P) full -> rows (k*3+m)*A+a
+            put(dev(params['envelope'][c]['sigma']).reshape(-1, nparam))
         self._packed, self._packed_key = flat, key
         return flat
 
@@ -285,8 +291,13 @@ class DeviceSystem:
         B = x.shape[0]
         p = self.pack_params(params)
         ws = self.workspace(B)
-        outs = [torch.empty(B, self.n_det, ns, ns, 2, dtype=self.dtype, device=self.device) if ns else None
-                for ns in self.nelec]
+        if self.net_kw.get('full_det', False):
+            sizes = [self.n, 0]
+        else:
+            sizes = list(self.nelec)
+        outs = [torch.empty(B, self.n_det, ns, ns, 2, dtype=self.dtype, device=self.device) if ns else None for ns in sizes]
+        if B == 0:
+            return [torch.view_as_complex(o) for o in outs if o is not None]
         _lib.check(self.lib.ds_orbitals(self.handle, _ptr(p), _ptr(x), B, _ptr(outs[0]), _ptr(outs[1]), _ptr(ws),
                                         ws.numel(), _stream()), 'ds_orbitals')
         return [torch.view_as_complex(o) for o in outs if o is not None]

@@ -144,7 +144,10 @@ def test_stages_vs_forward_laplacian_oracle(name):
             off += sysd.n_det * ns * ns * 2 * P
 
 
-@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'])
+OPTION_CASES = ['lih_fulldet', 'lih_diagenv', 'lih_fullenv', 'lih_bias', 'lih_fn_defaults', 'bcc_li_fulldet']
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'] + OPTION_CASES)
 def test_logpsi_and_orbitals_vs_reference_vectors(name):
     from deepsolid_amd import network
     fx, cell, klist, net_kw, params = load_case(name)
@@ -236,3 +239,22 @@ def test_float32_chain_vs_float64_oracle(name):
         ref = complex(ofl.stages(p_cpu, xb, klist, cell, net_kw)['ke'])
         assert abs(complex(ke[b].cpu()) - ref) < 2e-3 * max(1.0, abs(ref)), (complex(ke[b].cpu()), ref)
     assert np.abs(ew.cpu().numpy() - fx['ewald'][:nb].sum(-1)).max() < 2e-3 * max(1.0, np.abs(fx['ewald'][:nb].sum(-1)).max())
+
+
+@pytest.mark.parametrize('name', OPTION_CASES)
+def test_network_options_local_energy_vs_autodiff_oracle(name):
+    """full_det / diagonal and full envelopes / orbital bias / the factory's own defaults
+    (SURVEY section 8 row a9): E_kin against the oracle's autodiff restatement."""
+    from deepsolid_amd import hamiltonian, network
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    nb = 2
+    x = torch.as_tensor(fx['x'][:nb], device='cuda')
+    net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(dp, x)
+    onet_ = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    ke_o = oham.local_kinetic_energy_real_imag_hessian(onet_.apply)
+    for b in range(nb):
+        ref = complex(sum(ke_o(p_cpu, tt(fx['x'][b]))))
+        assert abs(complex(ke[b].cpu()) - ref) < 1e-8 * max(1.0, abs(ref)), (complex(ke[b].cpu()), ref)

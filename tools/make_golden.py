@@ -207,7 +207,10 @@ def main():
     out_dir = os.path.join(REPO, 'tests', 'golden')
     os.makedirs(out_dir, exist_ok=True)
 
+    only = set(sys.argv[1:])
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         my_cell = systems.SYSTEMS[case['system']](**case.get('system_kw', {}))
         prim0 = my_cell.original_cell
         # rebuild the cell with the REFERENCE's supercell code from primitive data only
