@@ -137,7 +137,8 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
     S.nch = d->n_dn > 0 ? 2 : 1;
     S.D = 3 * S.N + 2; S.P = rup(S.D, 16); S.NP = rup(S.N * S.N, 16);
     S.n_layers = d->n_layers; S.n_double = d->n_layers - 1;
-    S.h1[0] = 4 * S.A; S.h2[0] = 4;
+    S.dist_type = d->distance_type; S.nf = d->distance_type == 0 ? 4 : 7;
+    S.h1[0] = rup(S.nf * S.A, 4); S.h2[0] = rup(S.nf, 4);      // zero rows pad 'tri' (7 features) to the MFMA k-step
     int ldk = 0;
     for (int l = 0; l < d->n_layers; ++l) {
         S.h1[l + 1] = d->hidden_single[l];
@@ -313,7 +314,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     // 1. features
     {
         ProfScope ps(s, DS_PROF_FEATURES, st);
-        size_t sh = (size_t)(9 * S.N) * sizeof(T) + (size_t)S.N * S.A * 4 * sizeof(ds::Jet5<T>);
+        size_t sh = (size_t)(9 * S.N) * sizeof(T) + (size_t)S.N * S.A * S.nf * sizeof(ds::Jet5<T>);
         hipLaunchKernelGGL((ds::k_features<T>), dim3((unsigned)Bc), dim3(256), sh, st, S, x, blk(s->i_pi[0]), blk(s->i_sg[0]),
                            blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), c.G[0], c.MEAN[0], c.H2[0], c.Q);
     }
@@ -596,7 +597,8 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
 
 int check_arch(const ds_system_desc* d) {
     if (d->dtype != 0 && d->dtype != 1) return fail("dtype must be 0 (f64) or 1 (f32)");
-    if (d->distance_type != 0) return fail("only distance_type='nu' is implemented on the device");
+    if (d->distance_type != 0 && d->distance_type != 1) return fail("Unrecognized distance function.");
+    if (d->distance_type == 1 && d->envelope_type != 0) return fail("the 'tri' features support the isotropic envelope only");
     if (d->envelope_type < 0 || d->envelope_type > 2) return fail("unknown envelope_type");
     if (d->use_last_layer) return fail("use_last_layer=True is not implemented on the device");
     if (d->n_up < 1) return fail("n_up must be >= 1");

@@ -161,6 +161,47 @@ __device__ __forceinline__ void nu_distance_jet(const T r[3], const T* __restric
     }
 }
 
+// Trigonometric periodic distance of reference network.py:227-246 ('tri'), as jets in r:
+//   out[0] = sd, out[1..3] = sum_l sin(w_l) a_l, out[4..6] = sum_l cos(w_l) a_l        (7 features)
+template <typename T>
+__device__ __forceinline__ void tri_distance_jet(const T r[3], const T* __restrict__ av, const T* __restrict__ bv,
+                                                 int L, Jet5<T> out[7]) {
+    Jet5<T> Sn[6], Cn[6];
+    for (int l = 0; l < L; ++l) {
+        const T b0 = bv[3 * l], b1 = bv[3 * l + 1], b2 = bv[3 * l + 2];
+        const T w = r[0] * b0 + r[1] * b1 + r[2] * b2;
+        T sn, cs;
+        ds_sincos(w, &sn, &cs);
+        Jet5<T> wj; wj.v = w; wj.g[0] = b0; wj.g[1] = b1; wj.g[2] = b2; wj.l = 0;
+        Sn[l] = jet_fn(wj, sn, cs, -sn);
+        Cn[l] = jet_fn(wj, cs, -sn, -cs);
+    }
+    Jet5<T> s2 = jet_zero<T>();
+    for (int l = 0; l < L; ++l)
+        for (int m = 0; m < L; ++m) {
+            const T dot = av[3 * l] * av[3 * m] + av[3 * l + 1] * av[3 * m + 1] + av[3 * l + 2] * av[3 * m + 2];
+            Jet5<T> one = jet_zero<T>(); one.v = 1;
+            const Jet5<T> cl = jet_add(one, jet_scale(T(-1), Cn[l])), cm = jet_add(one, jet_scale(T(-1), Cn[m]));
+            s2 = jet_add(s2, jet_scale(dot, jet_add(jet_mul(cl, cm), jet_mul(Sn[l], Sn[m]))));
+        }
+    const T sd = ds_sqrt(s2.v);
+    out[0] = jet_fn(s2, sd, T(0.5) / sd, T(-0.25) / (sd * s2.v));
+    for (int c = 0; c < 3; ++c) {
+        Jet5<T> rs = jet_zero<T>(), rc = jet_zero<T>();
+        for (int l = 0; l < L; ++l) { rs = jet_add(rs, jet_scale(av[3 * l + c], Sn[l])); rc = jet_add(rc, jet_scale(av[3 * l + c], Cn[l])); }
+        out[1 + c] = rs;
+        out[4 + c] = rc;
+    }
+}
+
+// dist_type 0 = 'nu' (4 features), 1 = 'tri' (7 features); out has room for 7
+template <typename T>
+__device__ __forceinline__ void distance_jet(int dist_type, const T r[3], const T* __restrict__ av, const T* __restrict__ bv,
+                                             int L, Jet5<T> out[7]) {
+    if (dist_type == 0) nu_distance_jet(r, av, bv, L, out);
+    else tri_distance_jet(r, av, bv, L, out);
+}
+
 // x (Cartesian) -> wrapped into the cell: frac = x @ inv; frac - floor(frac); @ a   (network.py:42-57)
 template <typename T>
 __device__ __forceinline__ void wrap_point(const T x[3], const T* __restrict__ a, const T* __restrict__ ainv, T out[3],

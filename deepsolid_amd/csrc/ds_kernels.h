@@ -30,6 +30,7 @@ template <typename T> struct SysDev {
     int h2[DS_MAXL + 1];          // h2[0] = 4,  h2[l+1] = hidden_double[l]
     int ldk;                      // rows per electron in G
     int full_det, env_type, bias_orb;   // network options (network.py:609-621)
+    int dist_type, nf;            // 0 'nu' / 1 'tri'; features per atom or pair: 4 / 7 (rows padded to h1[0], h2[0])
     int norb[2];                  // orbitals per determinant seen by spin s: n_s, or N with full_det
     int n_detch;                  // determinant channels: one per active spin, or 1 with full_det
     int det_n[2];                 // matrix size of channel ch
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
     T* xs = reinterpret_cast<T*>(smem_raw);        // [N][3] raw
     T* px = xs + 3 * S.N;                          // [N][3] wrapped into the primitive cell
     T* sx = px + 3 * S.N;                          // [N][3] wrapped into the simulation cell
-    Jet5<T>* jea = reinterpret_cast<Jet5<T>*>(sx + 3 * S.N);   // [N*A][4]
+    Jet5<T>* jea = reinterpret_cast<Jet5<T>*>(sx + 3 * S.N);   // [N*A][nf]
     const int w = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int N = S.N, A = S.A, P = S.P, NP = S.NP;
     const T* xw = x + (size_t)w * 3 * N;
@@ -73,58 +74,62 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
     }
     __syncthreads();
     // electron-atom jets
+    const int nf = S.nf;
     for (int ia = tid; ia < N * A; ia += nt) {
         const int i = ia / A, a = ia % A;
         T r[3];
         for (int c = 0; c < 3; ++c) r[c] = px[3 * i + c] - S.atoms[3 * a + c];
-        Jet5<T> o[4];
-        nu_distance_jet(r, S.prim_AV, S.prim_BV, S.L, o);
-        for (int f = 0; f < 4; ++f) jea[4 * ia + f] = o[f];
+        Jet5<T> o[7];
+        distance_jet(S.dist_type, r, S.prim_AV, S.prim_BV, S.L, o);
+        for (int f = 0; f < nf; ++f) jea[nf * ia + f] = o[f];
     }
     __syncthreads();
-    const int K1 = 4 * A;
-    // one-electron stream rows of G: row k = 4a+f = [sd, rel_x, rel_y, rel_z] per atom (network.py:503-504)
+    const int K1 = S.h1[0];      // nf * A rounded up to a multiple of 4 (zero rows pad)
+    // one-electron stream rows of G: row k = nf*a + f = [sd, rel...] per atom (network.py:503-504)
     T* Gw = G + (size_t)w * N * S.ldk * P;
     for (int idx = tid; idx < N * K1 * P; idx += nt) {
         const int slot = idx % P, k = (idx / P) % K1, i = idx / (P * K1);
-        const Jet5<T>& j = jea[4 * (i * A + k / 4) + (k & 3)];
         T v = 0;
-        if (slot == 0) v = j.v;
-        else if (slot == 1) v = j.l;
-        else if (slot < S.D && (slot - 2) / 3 == i) v = j.g[(slot - 2) % 3];
+        if (k < nf * A) {
+            const Jet5<T>& j = jea[nf * (i * A + k / nf) + (k % nf)];
+            if (slot == 0) v = j.v;
+            else if (slot == 1) v = j.l;
+            else if (slot < S.D && (slot - 2) / 3 == i) v = j.g[(slot - 2) % 3];
+        }
         Gw[((size_t)i * S.ldk + k) * P + slot] = v;
     }
     // spin means of the one-electron stream
-    T* Mw = MEAN + (size_t)w * S.nch * S.h1[0] * P;   // stride uses this layer's K1
+    T* Mw = MEAN + (size_t)w * S.nch * K1 * P;
     for (int idx = tid; idx < S.nch * K1 * P; idx += nt) {
         const int slot = idx % P, k = (idx / P) % K1, s = idx / (P * K1);
         const int i0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
-        const int a = k / 4, f = k & 3;
+        const int a = k / nf, f = k % nf;
         T v = 0;
-        if (slot < 2) {
-            for (int i = i0; i < i0 + ns; ++i) v += (slot == 0 ? jea[4 * (i * A + a) + f].v : jea[4 * (i * A + a) + f].l);
-        } else if (slot < S.D) {
-            const int j = (slot - 2) / 3;
-            if (j >= i0 && j < i0 + ns) v = jea[4 * (j * A + a) + f].g[(slot - 2) % 3];
+        if (k < nf * A) {
+            if (slot < 2) {
+                for (int i = i0; i < i0 + ns; ++i) v += (slot == 0 ? jea[nf * (i * A + a) + f].v : jea[nf * (i * A + a) + f].l);
+            } else if (slot < S.D) {
+                const int j = (slot - 2) / 3;
+                if (j >= i0 && j < i0 + ns) v = jea[nf * (j * A + a) + f].g[(slot - 2) % 3];
+            }
         }
         Mw[idx] = v / T(ns);
     }
     // two-electron stream (pair features of r = x_i - x_j in the simulation cell; diagonal masked,
-    // network.py:294-300)
-    T* Hw = H2 + (size_t)w * S.h2[0] * 5 * NP;   // caller passes stride for 4 rows via h2[0]
+    // network.py:294-300); rows nf..h2[0]-1 are zero padding
+    T* Hw = H2 + (size_t)w * S.h2[0] * 5 * NP;
     // stored pair index q = e*N + j holds h2[j][e] (first electron j, second electron e), r = x_j - x_e:
     // network.py:323-328 averages over the FIRST index, so electron e's partners are contiguous.
     for (int pr = tid; pr < NP; pr += nt) {
         const int e = pr / N, j = pr % N;
-        Jet5<T> o[4];
+        Jet5<T> o[8];
+        for (int f = 0; f < 8; ++f) o[f] = jet_zero<T>();
         if (pr < N * N && e != j) {
             T r[3];
             for (int c = 0; c < 3; ++c) r[c] = sx[3 * j + c] - sx[3 * e + c];
-            nu_distance_jet(r, S.sim_AV, S.sim_BV, S.L, o);
-        } else {
-            for (int f = 0; f < 4; ++f) o[f] = jet_zero<T>();
+            distance_jet(S.dist_type, r, S.sim_AV, S.sim_BV, S.L, o);
         }
-        for (int f = 0; f < 4; ++f) {
+        for (int f = 0; f < S.h2[0]; ++f) {
             Hw[(size_t)(f * 5 + 0) * NP + pr] = o[f].v;
             Hw[(size_t)(f * 5 + 1) * NP + pr] = o[f].g[0];
             Hw[(size_t)(f * 5 + 2) * NP + pr] = o[f].g[1];
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
         for (int a = 0; a < A; ++a) {
             const T pw = pi_[a * np + p];
             if (S.env_type == 0) {            // isotropic (network.py:335-337): exp(-|sd sigma|)
-                const Jet5<T>& sd = jea[4 * (i * A + a)];
+                const Jet5<T>& sd = jea[nf * (i * A + a)];
                 const T sg = sg_[a * np + p];
                 const T u = sd.v * sg;
                 const T ex = pw * ds_exp(-ds_abs(u));
@@ -154,9 +159,9 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
                 Jet5<T> r2 = jet_zero<T>();
                 for (int m = 0; m < 3; ++m) {
                     Jet5<T> u = jet_zero<T>();
-                    if (S.env_type == 1) u = jet_scale(sg_[(a * 3 + m) * np + p], jea[4 * (i * A + a) + 1 + m]);
+                    if (S.env_type == 1) u = jet_scale(sg_[(a * 3 + m) * np + p], jea[nf * (i * A + a) + 1 + m]);
                     else
-                        for (int k = 0; k < 3; ++k) u = jet_add(u, jet_scale(sg_[((k * 3 + m) * A + a) * np + p], jea[4 * (i * A + a) + 1 + k]));
+                        for (int k = 0; k < 3; ++k) u = jet_add(u, jet_scale(sg_[((k * 3 + m) * A + a) * np + p], jea[nf * (i * A + a) + 1 + k]));
                     r2 = jet_add(r2, jet_mul(u, u));
                 }
                 const T r = ds_sqrt(r2.v);

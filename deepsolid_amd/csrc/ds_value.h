@@ -43,6 +43,26 @@ __device__ __forceinline__ void nu_distance_val(const T r[3], const T* __restric
     }
 }
 
+// value of the 'tri' features (network.py:227-246): [sd, sin-rel (3), cos-rel (3)]
+template <typename T>
+__device__ __forceinline__ void tri_distance_val(const T r[3], const T* __restrict__ av, const T* __restrict__ bv, int L,
+                                                 T out[7]) {
+    T sn[6], cs[6];
+    for (int l = 0; l < L; ++l) ds_sincos(r[0] * bv[3 * l] + r[1] * bv[3 * l + 1] + r[2] * bv[3 * l + 2], &sn[l], &cs[l]);
+    T s2 = 0;
+    for (int l = 0; l < L; ++l)
+        for (int m = 0; m < L; ++m)
+            s2 += (av[3 * l] * av[3 * m] + av[3 * l + 1] * av[3 * m + 1] + av[3 * l + 2] * av[3 * m + 2]) *
+                  ((1 - cs[l]) * (1 - cs[m]) + sn[l] * sn[m]);
+    out[0] = ds_sqrt(s2);
+    for (int c = 0; c < 3; ++c) {
+        T a = 0, b = 0;
+        for (int l = 0; l < L; ++l) { a += av[3 * l + c] * sn[l]; b += av[3 * l + c] * cs[l]; }
+        out[1 + c] = a;
+        out[4 + c] = b;
+    }
+}
+
 // grid (groups), block 256.  Phase 1 writes the one-electron features and the pair features,
 // phase 2 (after a block barrier; same CU, so the rows just written are visible) the spin means and Q.
 template <typename T>
@@ -51,32 +71,38 @@ __global__ void __launch_bounds__(256) k_features_val(SysDev<T> S, const T* __re
                                                       const T* __restrict__ env_sg1, T* __restrict__ G, T* __restrict__ MEAN,
                                                       T* __restrict__ H2, T* __restrict__ Q) {
     const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-    const int N = S.N, A = S.A, NP = S.NP, K1 = 4 * A;
+    const int N = S.N, A = S.A, NP = S.NP, K1 = S.h1[0], nf = S.nf;
     T* Gw = G + (size_t)g * N * S.ldk * PV;
     auto walker = [&](int c) { long wi = (long)g * PV + c; return wi < B ? wi : B - 1; };
     for (int idx = tid; idx < N * A * PV; idx += nt) {
         const int c = idx % PV, a = (idx / PV) % A, i = idx / (PV * A);
         const T* xp = x + (size_t)walker(c) * 3 * N + 3 * i;
-        T r[3] = {xp[0], xp[1], xp[2]}, o[3], wr[3], f[4];
+        T r[3] = {xp[0], xp[1], xp[2]}, o[3], wr[3], f[7];
         wrap_point(r, S.prim_a, S.prim_ainv, o, wr);
         for (int k = 0; k < 3; ++k) o[k] -= S.atoms[3 * a + k];
-        nu_distance_val(o, S.prim_AV, S.prim_BV, S.L, f);
-        for (int k = 0; k < 4; ++k) Gw[((size_t)i * S.ldk + 4 * a + k) * PV + c] = f[k];
+        if (S.dist_type == 0) nu_distance_val(o, S.prim_AV, S.prim_BV, S.L, f);
+        else tri_distance_val(o, S.prim_AV, S.prim_BV, S.L, f);
+        for (int k = 0; k < nf; ++k) Gw[((size_t)i * S.ldk + nf * a + k) * PV + c] = f[k];
+    }
+    for (int idx = tid; idx < N * (K1 - nf * A) * PV; idx += nt) {       // zero padding rows
+        const int c = idx % PV, k = nf * A + (idx / PV) % (K1 - nf * A), i = idx / (PV * (K1 - nf * A));
+        Gw[((size_t)i * S.ldk + k) * PV + c] = 0;
     }
     for (int idx = tid; idx < PV * NP; idx += nt) {
         const int q = idx % NP, c = idx / NP;
         const int e = q / N, j = q % N;
-        T f[4] = {0, 0, 0, 0};
+        T f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (q < N * N && e != j) {
             const T* xw = x + (size_t)walker(c) * 3 * N;
             T rj[3] = {xw[3 * j], xw[3 * j + 1], xw[3 * j + 2]}, re[3] = {xw[3 * e], xw[3 * e + 1], xw[3 * e + 2]}, oj[3], oe[3], wr[3];
             wrap_point(rj, S.sim_a, S.sim_ainv, oj, wr);
             wrap_point(re, S.sim_a, S.sim_ainv, oe, wr);
             for (int k = 0; k < 3; ++k) oj[k] -= oe[k];
-            nu_distance_val(oj, S.sim_AV, S.sim_BV, S.L, f);
+            if (S.dist_type == 0) nu_distance_val(oj, S.sim_AV, S.sim_BV, S.L, f);
+            else tri_distance_val(oj, S.sim_AV, S.sim_BV, S.L, f);
         }
         T* Hw = H2 + (size_t)(g * (PV / 5) + c / 5) * S.h2[0] * 5 * NP;
-        for (int k = 0; k < 4; ++k) Hw[(size_t)(k * 5 + c % 5) * NP + q] = f[k];
+        for (int k = 0; k < S.h2[0]; ++k) Hw[(size_t)(k * 5 + c % 5) * NP + q] = f[k];
     }
     __syncthreads();
     T* Mw = MEAN + (size_t)g * S.nch * K1 * PV;
@@ -96,7 +122,7 @@ __global__ void __launch_bounds__(256) k_features_val(SysDev<T> S, const T* __re
         const T* sg_ = s == 0 ? env_sg0 : env_sg1;
         T e = 0;
         for (int a = 0; a < A; ++a) {
-            const T* f = Gw + ((size_t)i * S.ldk + 4 * a) * PV + c;     // rows sd, rel_x, rel_y, rel_z of atom a
+            const T* f = Gw + ((size_t)i * S.ldk + nf * a) * PV + c;    // rows sd, rel_x, rel_y, rel_z (, cos-rel) of atom a
             T r;
             if (S.env_type == 0) r = ds_abs(f[0] * sg_[a * np + p]);
             else {

@@ -198,18 +198,29 @@ class DeviceSystem:
                 raise ValueError(f'parameter block shape {tuple(mat.shape)} != expected {(rows, cols)}')
             flat[off:off + rows * cols] = mat.reshape(-1)
         natom = np.asarray(self.cell.original_cell.atom_coords()).reshape(-1, 3).shape[0]
-        h1 = [4 * natom] + [h[0] for h in self.hidden_dims]
-        h2 = [4] + [h[1] for h in self.hidden_dims]
+        nf = 4 if self.net_kw.get('distance_type', 'nu') == 'nu' else 7
+        r4 = lambda v: (v + 3) // 4 * 4
+        # reference widths (network.py:111-132) and the device widths (layer-0 rows padded to the MFMA k-step)
+        h1_ref = [nf * natom] + [h[0] for h in self.hidden_dims]
+        h2_ref = [nf] + [h[1] for h in self.hidden_dims]
+        h1 = [r4(nf * natom)] + h1_ref[1:]
+        h2 = [r4(nf)] + h2_ref[1:]
+
+        def pad_rows(m, rows):
+            if m.shape[0] == rows:
+                return m
+            return torch.cat([m, torch.zeros(rows - m.shape[0], m.shape[1], dtype=m.dtype, device=m.device)], dim=0)
         for l in range(len(self.hidden_dims)):
             w = dev(params['single'][l]['w'])
-            kh, k2 = h1[l], h2[l]
+            kh, k2, khp, k2p = h1_ref[l], h2_ref[l], h1[l], h2[l]
             if w.shape[0] != (nch + 1) * kh + nch * k2:
                 raise ValueError(f"single[{l}]['w'] has {w.shape[0]} rows, expected {(nch + 1) * kh + nch * k2}")
-            put(torch.cat([w[:kh], w[(nch + 1) * kh:]], dim=0))          # per-electron rows
-            put(w[kh:(nch + 1) * kh])                                    # spin-mean rows
+            m2 = [pad_rows(w[(nch + 1) * kh + c * k2:(nch + 1) * kh + (c + 1) * k2], k2p) for c in range(nch)]
+            put(torch.cat([pad_rows(w[:kh], khp)] + m2, dim=0))                       # per-electron rows [h | m2_up | m2_dn]
+            put(torch.cat([pad_rows(w[(1 + c) * kh:(2 + c) * kh], khp) for c in range(nch)], dim=0))   # spin-mean rows
             put(dev(params['single'][l]['b']))
         for l in range(len(self.hidden_dims) - 1):
-            put(dev(params['double'][l]['w']))
+            put(pad_rows(dev(params['double'][l]['w']), h2[l]))
             put(dev(params['double'][l]['b']))
         full_det = bool(self.net_kw.get('full_det', False))
         for c in range(nch):
