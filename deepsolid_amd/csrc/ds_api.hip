@@ -64,7 +64,8 @@ struct ds_system {
     WsLayout ws;                      // forward-Laplacian chain, per walker
     WsLayout wsv;                     // value chain, per group of PV walkers
     // block indices
-    std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_borb, i_pi, i_sg;
+    std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_wsh_orb, i_borb, i_pi, i_sg;
+    bool use_last = false;
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[DS_PROF_KINDS];
@@ -136,7 +137,7 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
     S.N = d->n_up + d->n_dn; S.n_up = d->n_up; S.n_dn = d->n_dn; S.A = d->n_atoms_prim; S.L = d->n_sym; S.K = d->n_det;
     S.nch = d->n_dn > 0 ? 2 : 1;
     S.D = 3 * S.N + 2; S.P = rup(S.D, 16); S.NP = rup(S.N * S.N, 16);
-    S.n_layers = d->n_layers; S.n_double = d->n_layers - 1;
+    S.n_layers = d->n_layers; S.n_double = d->use_last_layer ? d->n_layers : d->n_layers - 1;   // network.py:134
     S.dist_type = d->distance_type; S.nf = d->distance_type == 0 ? 4 : 7;
     S.h1[0] = rup(S.nf * S.A, 4); S.h2[0] = rup(S.nf, 4);      // zero rows pad 'tri' (7 features) to the MFMA k-step
     int ldk = 0;
@@ -145,7 +146,7 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
         S.h2[l + 1] = d->hidden_double[l];
         ldk = std::max(ldk, S.h1[l] + S.nch * S.h2[l]);
     }
-    ldk = std::max(ldk, S.h1[d->n_layers]);
+    ldk = std::max(ldk, S.h1[d->n_layers] + (d->use_last_layer ? S.nch * S.h2[d->n_layers] : 0));
     S.ldk = ldk;
     S.full_det = d->full_det; S.env_type = d->envelope_type; S.bias_orb = d->bias_orbitals;
     if (d->full_det) {
@@ -194,7 +195,9 @@ void build_layouts(ds_system* s) {
         s->i_b2.push_back(add(1, S.h2[l + 1]));
     }
     for (int c = 0; c < S.nch; ++c) {
-        s->i_worb.push_back(add(S.h1[S.n_layers], S.ocols[c]));
+        // network.py:129-130,178: with use_last_layer the orbital head takes the symmetric features (h | means | pair means)
+        s->i_worb.push_back(add(S.h1[S.n_layers] + (s->use_last ? S.nch * S.h2[S.n_layers] : 0), S.ocols[c]));
+        s->i_wsh_orb.push_back(s->use_last ? add(S.nch * S.h1[S.n_layers], S.ocols[c]) : -1);
         s->i_borb.push_back(S.bias_orb ? add(1, 2 * S.nparam[c]) : -1);
         s->i_pi.push_back(add(S.A, S.nparam[c]));
         const int sig_rows = S.env_type == 0 ? S.A : (S.env_type == 1 ? 3 * S.A : 9 * S.A);   // network.py:146-152
@@ -206,7 +209,7 @@ void build_layouts(ds_system* s) {
     for (int l = 0; l <= S.n_layers; ++l) { h1max = std::max(h1max, S.h1[l]); h2max = std::max(h2max, S.h2[l]); }
     w.G = (size_t)S.N * S.ldk * S.P;
     w.MEAN = (size_t)S.nch * h1max * S.P;
-    w.ZB = (size_t)h1max * S.P;                      // shared spin-mean term S of one layer
+    w.ZB = (size_t)std::max(h1max, std::max(S.ocols[0], S.ocols[1])) * S.P;   // shared spin-mean term S of one layer / orbital head
     for (int c = 0; c < S.nch; ++c)                  // ... or the orbital GEMM output of one spin
         w.ZB = std::max(w.ZB, (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * S.P);
     w.H2 = (size_t)h2max * 5 * S.NP;
@@ -228,8 +231,8 @@ void build_layouts(ds_system* s) {
     v = w;
     v.G = (size_t)S.N * S.ldk * PV;
     v.MEAN = (size_t)S.nch * h1max * PV;
-    v.ZB = (size_t)h1max * PV;
-    for (int c = 0; c < S.nch; ++c) v.ZB = std::max(v.ZB, (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * PV);
+    v.ZB = (size_t)std::max(h1max, std::max(S.ocols[0], S.ocols[1])) * PV;
+    for (int c = 0; c < S.nch; ++c) v.ZB = std::max(v.ZB, (size_t)((c == 0 ? S.n_up : S.n_dn) + 1) * S.ocols[c] * PV);
     v.H2 = (size_t)(PV / 5) * h2max * 5 * S.NP;
     v.Q = (size_t)S.N * S.nparam_max * 2 * PV;
     mo = 0;
@@ -388,20 +391,32 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     }
     if (stop == STOP_G0 + S.n_layers) return copy_out(dr, c.G[gi], L.G * Bc, st);
     // orbitals: GEMM over the electrons of one spin with the envelope/phase product rule fused in
+    const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
+    if (s->use_last) {
+        ProfScope ps(s, DS_PROF_M2_EXPAND, st);
+        hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc), dim3(256), (size_t)(K2l * 5 * S.N + S.nch * K2l * 5) * sizeof(T), st, S,
+                           c.H2[hi], K2l, c.G[gi], Kl);
+    }
     for (int sp = 0; sp < S.nch; ++sp) {
-        const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp], Kh = S.h1[S.n_layers];
+        const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
+        const int Korb = Kl + (s->use_last ? S.nch * K2l : 0);
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
-            ProfScope ps(s, DS_PROF_ORBITAL, st);
             dim3 block; unsigned gz;
             gemm_geom(OC, NB, &block, &gz);
+            if (s->use_last) {
+                ProfScope ps(s, DS_PROF_SHARED_TERM, st);
+                hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, gz), block, 2 * 16 * S.P * sizeof(T), st, S, c.G[gi],
+                                   blk(s->i_wsh_orb[sp]), Kl, c.ZB, OC, S.P);
+            }
+            ProfScope ps(s, DS_PROF_ORBITAL, st);
             const int ch = S.mat_ch[sp];
             ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
                              S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr};
             hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 5>), dim3(ns, (unsigned)Bc, gz), block, 0, st,
                                c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
-                               blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
-                               (size_t)0, OC, S.P, (const T*)nullptr, (const T*)nullptr, oe);
+                               blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
+                               (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
         });
         if (rc) return fail("no orbital kernel instance for %d slot tiles", S.P / 16);
     }
@@ -500,15 +515,24 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void*
         gi ^= 1;
         if (l < S.n_double) hi ^= 1;
     }
+    const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
+    if (s->use_last) hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, H2[hi], K2l, G[gi], Kl);
+    // PHI (GEMM output) and the orbital shared term both live in ZB: PHI first, S behind it
     for (int sp = 0; sp < S.nch; ++sp) {
-        const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp], Kh = S.h1[S.n_layers];
+        const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
+        const int Korb = Kl + (s->use_last ? S.nch * K2l : 0);
         dim3 oblock; unsigned ogz;
         gemm_geom(OC, 4, &oblock, &ogz);
+        T* Sorb = ZB + (size_t)ns * OC * PV * ng;
+        if (s->use_last)
+            hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, ogz), oblock, 2 * 16 * PV * sizeof(T), st, S, G[gi],
+                               blk(s->i_wsh_orb[sp]), Kl, Sorb, OC, PV);
         hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, G[gi] + (size_t)i0 * S.ldk * PV,
-                           gws, gts, blk(s->i_worb[sp]), Kh, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, ZB, (size_t)ns * OC * PV,
+                           gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, ZB, (size_t)ns * OC * PV,
                            OC, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
         hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, ZB, (size_t)ns * OC * PV, Q, MOUT, sp,
-                           L.MOUT, L.mout_off[S.mat_ch[sp]], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr);
+                           L.MOUT, L.mout_off[S.mat_ch[sp]], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr,
+                           s->use_last ? (const T*)Sorb : (const T*)nullptr);
     }
     if (mout_ptr) *mout_ptr = MOUT;
     if (out_logabs || out_phase) {
@@ -600,7 +624,6 @@ int check_arch(const ds_system_desc* d) {
     if (d->distance_type != 0 && d->distance_type != 1) return fail("Unrecognized distance function.");
     if (d->distance_type == 1 && d->envelope_type != 0) return fail("the 'tri' features support the isotropic envelope only");
     if (d->envelope_type < 0 || d->envelope_type > 2) return fail("unknown envelope_type");
-    if (d->use_last_layer) return fail("use_last_layer=True is not implemented on the device");
     if (d->n_up < 1) return fail("n_up must be >= 1");
     if (d->n_dn > d->n_up) return fail("n_dn > n_up is not supported");
     if (d->n_layers < 1 || d->n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
@@ -626,6 +649,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     ds_system* s = new ds_system();
     s->d = *desc;
     s->dtype = desc->dtype;
+    s->use_last = desc->use_last_layer != 0;
     std::vector<double> h64;
     std::vector<float> h32;
     fill_tables<double>(s, desc, s->sd, h64);

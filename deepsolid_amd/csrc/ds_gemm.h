@@ -144,6 +144,12 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 Cx<T> phi[ST];
 #pragma unroll
                 for (int s = 0; s < ST; ++s) phi[s] = Cx<T>(acc[a][s][2 * ab], acc[a][s][2 * ab + 1]);
+                if (Sb) {   // use_last_layer: the orbital input has spin-mean rows too (network.py:535) -> shared term
+                    const T* Sr = Sb + (size_t)w * Nout * P + (size_t)(n0 + 16 * a + acc_row<T>(lane, 2 * ab)) * P + lr;
+                    const T* Si = Sb + (size_t)w * Nout * P + (size_t)(n0 + 16 * a + acc_row<T>(lane, 2 * ab + 1)) * P + lr;
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) { phi[s].re += Sr[16 * s]; phi[s].im += Si[16 * s]; }
+                }
                 if (oe.bias && valid && lr == 0) { phi[0].re += oe.bias[p]; phi[0].im += oe.bias[oe.nparam + p]; }
                 const Cx<T> f0(__shfl(phi[0].re, base), __shfl(phi[0].im, base));
                 const Cx<T> fL(__shfl(phi[0].re, base | 1), __shfl(phi[0].im, base | 1));

@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __r
 template <typename T>
 __global__ void __launch_bounds__(256) k_orbital_epilogue_val(SysDev<T> S, const T* __restrict__ PHI, size_t phi_group_stride,
                                                               const T* __restrict__ Q, T* __restrict__ MOUT, int sp,
-                                                              size_t mout_stride, size_t mout_off, const T* __restrict__ bias) {
+                                                              size_t mout_stride, size_t mout_off, const T* __restrict__ bias,
+                                                              const T* __restrict__ Sb) {
     const int ii = blockIdx.x, g = blockIdx.y, N = S.N, OC = S.ocols[sp];
     const int i0 = sp == 0 ? 0 : S.n_up, nparam = S.nparam[sp], i = i0 + ii;
     const int norb = S.norb[sp], n = S.det_n[S.mat_ch[sp]], row = S.row_off[sp] + ii;
@@ -176,6 +177,7 @@ __global__ void __launch_bounds__(256) k_orbital_epilogue_val(SysDev<T> S, const
     for (int idx = threadIdx.x; idx < nparam * PV; idx += blockDim.x) {
         const int c = idx % PV, p = idx / PV;
         Cx<T> phi(Pw[(size_t)orb_col<T>(p, 0) * PV + c], Pw[(size_t)orb_col<T>(p, 1) * PV + c]);
+        if (Sb) { phi.re += Sb[((size_t)g * OC + orb_col<T>(p, 0)) * PV + c]; phi.im += Sb[((size_t)g * OC + orb_col<T>(p, 1)) * PV + c]; }
         if (bias) { phi.re += bias[p]; phi.im += bias[nparam + p]; }
         const Cx<T> q(Qw[(size_t)(p * 2) * PV + c], Qw[(size_t)(p * 2 + 1) * PV + c]);
         const Cx<T> v = phi * q;

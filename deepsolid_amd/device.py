@@ -219,7 +219,8 @@ class DeviceSystem:
             put(torch.cat([pad_rows(w[:kh], khp)] + m2, dim=0))                       # per-electron rows [h | m2_up | m2_dn]
             put(torch.cat([pad_rows(w[(1 + c) * kh:(2 + c) * kh], khp) for c in range(nch)], dim=0))   # spin-mean rows
             put(dev(params['single'][l]['b']))
-        for l in range(len(self.hidden_dims) - 1):
+        use_last = bool(self.net_kw.get('use_last_layer', False))
+        for l in range(len(self.hidden_dims) - (0 if use_last else 1)):
             put(pad_rows(dev(params['double'][l]['w']), h2[l]))
             put(dev(params['double'][l]['b']))
         full_det = bool(self.net_kw.get('full_det', False))
@@ -229,13 +230,22 @@ class DeviceSystem:
             w = dev(params['orbital'][c]['w'])
             if w.shape[1] != 2 * nparam:
                 raise ValueError(f"orbital[{c}]['w'] has {w.shape[1]} columns, expected {2 * nparam}")
-            off, rows, cols = next(bi)
-            src = self._orbital_column_map(nparam, cols)
-            packed = torch.zeros(rows, cols, dtype=self.dtype, device=self.device)
-            valid = src >= 0
-            packed[:, torch.as_tensor(np.nonzero(valid)[0], device=self.device)] = \
-                w[:, torch.as_tensor(src[valid], device=self.device)]
-            flat[off:off + rows * cols] = packed.reshape(-1)
+            def put_packed(mat):
+                off, rows, cols = next(bi)
+                src = self._orbital_column_map(nparam, cols)
+                if mat.shape[0] != rows:
+                    raise ValueError(f"orbital[{c}]['w'] block has {mat.shape[0]} rows, expected {rows}")
+                packed = torch.zeros(rows, cols, dtype=self.dtype, device=self.device)
+                valid = src >= 0
+                packed[:, torch.as_tensor(np.nonzero(valid)[0], device=self.device)] = \
+                    mat[:, torch.as_tensor(src[valid], device=self.device)]
+                flat[off:off + rows * cols] = packed.reshape(-1)
+            kh, k2 = h1[-1], h2[-1]
+            if use_last:      # rows [h | mean_up | mean_dn | m2_up | m2_dn] (network.py:126-128) -> per-electron / shared
+                put_packed(torch.cat([w[:kh], w[(nch + 1) * kh:]], dim=0))
+                put_packed(w[kh:(nch + 1) * kh])
+            else:
+                put_packed(w)
             if self.net_kw.get('bias_orbitals', False):
                 put(dev(params['orbital'][c]['b']))
             put(dev(params['envelope'][c]['pi']))

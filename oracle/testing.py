@@ -70,6 +70,7 @@ CASES = {
     'lih_tri':       dict(system='lih', seed=20, batch=3, net_kw=dict(distance_type='tri'), mcmc=False),
     'lih_diagenv':   dict(system='lih', seed=21, batch=3, net_kw=dict(envelope_type='diagonal'), mcmc=False),
     'lih_fullenv':   dict(system='lih', seed=22, batch=3, net_kw=dict(envelope_type='full'), mcmc=False),
+    'lih_lastlayer': dict(system='lih', seed=26, batch=3, net_kw=dict(use_last_layer=True), mcmc=False),
     'lih_bias':      dict(system='lih', seed=23, batch=3, net_kw=dict(bias_orbitals=True), mcmc=False),
     # the defaults of the make_solid_fermi_net SIGNATURE (network.py:609-621), not of base_config.py
     'lih_fn_defaults': dict(system='lih', seed=24, batch=3, mcmc=False,

@@ -144,7 +144,7 @@ def test_stages_vs_forward_laplacian_oracle(name):
             off += sysd.n_det * ns * ns * 2 * P
 
 
-OPTION_CASES = ['lih_tri', 'lih_fulldet', 'lih_diagenv', 'lih_fullenv', 'lih_bias', 'lih_fn_defaults', 'bcc_li_fulldet']
+OPTION_CASES = ['lih_lastlayer', 'lih_tri', 'lih_fulldet', 'lih_diagenv', 'lih_fullenv', 'lih_bias', 'lih_fn_defaults', 'bcc_li_fulldet']
 
 
 @pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'] + OPTION_CASES)
