@@ -45,6 +45,7 @@ SIGNATURES = {
     'ds_param_layout': (C.c_int, [_VP, C.POINTER(ParamBlock), C.c_int]),
     'ds_workspace_bytes': (C.c_int64, [_VP, C.c_int64]),
     'ds_logpsi': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, C.c_int64, _VP]),
+    'ds_logpsi_grad': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     'ds_orbitals': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, C.c_int64, _VP]),
     'ds_ewald': (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP]),
     'ds_local_energy': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),

@@ -308,7 +308,7 @@ int copy_out(DumpReq<T>* dr, const T* src, size_t n, hipStream_t st) {
 // The forward-Laplacian chain on a chunk of Bc walkers.
 template <typename T>
 int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, hipStream_t st, T* out_ke, T* out_logabs,
-              T* out_phase, DumpReq<T>* dr) {
+              T* out_phase, DumpReq<T>* dr, T* out_grad = nullptr) {
     const ds::SysDev<T>& S = dev<T>(s);
     const WsLayout& L = s->ws;
     Carve<T> c = carve<T>(s, ws, Bc);
@@ -453,7 +453,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     {
         ProfScope ps(s, DS_PROF_COMBINE, st);
         hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, c.TR, L.TR, L.tr_off[1], c.DETS, L.DETS,
-                           L.dets_off[1], out_ke, out_logabs, out_phase);
+                           L.dets_off[1], out_ke, out_logabs, out_phase, out_grad);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -544,7 +544,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void*
                                (T*)nullptr, (size_t)0, (size_t)0, DETS, dstride, s->ws.dets_off[sp], PV, PV);
         }
         hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, (const T*)nullptr, (size_t)0, (size_t)0, DETS, dstride,
-                           s->ws.dets_off[1], (T*)nullptr, out_logabs, out_phase);
+                           s->ws.dets_off[1], (T*)nullptr, out_logabs, out_phase, (T*)nullptr);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -616,6 +616,21 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
         }
     }
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int logpsi_grad_impl(ds_system* s, const void* params, const void* x, int64_t B, void* out_logabs, void* out_phase, void* out_grad,
+                     void* ws, int64_t ws_bytes, hipStream_t st) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T));
+    if (chunk < 1) return fail("workspace too small");
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t Bc = std::min(chunk, B - b0);
+        int rc = run_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, ws, st, nullptr, out_logabs ? (T*)out_logabs + b0 : nullptr,
+                              out_phase ? (T*)out_phase + 2 * b0 : nullptr, nullptr, (T*)out_grad + b0 * 3 * S.N * 2);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -707,6 +722,15 @@ int ds_logpsi(ds_system* s, const void* params, const void* x, int64_t B, void* 
     hipStream_t st = (hipStream_t)stream;
     return s->dtype == 0 ? logpsi_impl<double>(s, params, x, B, out_logabs, out_phase, ws, ws_bytes, st)
                          : logpsi_impl<float>(s, params, x, B, out_logabs, out_phase, ws, ws_bytes, st);
+}
+
+int ds_logpsi_grad(ds_system* s, const void* params, const void* x, int64_t B, void* out_logabs, void* out_phase, void* out_grad,
+                   void* ws, int64_t ws_bytes, void* stream) {
+    if (!s || !params || !x || !ws || !out_grad) return fail("null argument");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return s->dtype == 0 ? logpsi_grad_impl<double>(s, params, x, B, out_logabs, out_phase, out_grad, ws, ws_bytes, st)
+                         : logpsi_grad_impl<float>(s, params, x, B, out_logabs, out_phase, out_grad, ws, ws_bytes, st);
 }
 
 int ds_ewald(ds_system* s, const void* x, int64_t B, void* out, void* stream) {

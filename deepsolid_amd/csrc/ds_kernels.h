@@ -446,7 +446,8 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
 template <typename T>
 __global__ void __launch_bounds__(64) k_combine(SysDev<T> S, const T* __restrict__ TR, size_t tr_stride, size_t tr_off1,
                                                 const T* __restrict__ DETS, size_t dets_stride, size_t dets_off1,
-                                                T* __restrict__ out_ke, T* __restrict__ out_logabs, T* __restrict__ out_phase) {
+                                                T* __restrict__ out_ke, T* __restrict__ out_logabs, T* __restrict__ out_phase,
+                                                T* __restrict__ out_grad) {
     const int w = blockIdx.x, lane = threadIdx.x;
     const int P = S.P, K = S.K;
     const T* Tw = TR + (size_t)w * tr_stride;
@@ -484,6 +485,18 @@ __global__ void __launch_bounds__(64) k_combine(SysDev<T> S, const T* __restrict
             lap = lap + Cx<T>(Tw[tr_off1 + (size_t)(k * 2) * P + 1] - Dw[dets_off1 + 4 * k + 2],
                               Tw[tr_off1 + (size_t)(k * 2 + 1) * P + 1] - Dw[dets_off1 + 4 * k + 3]);
         ke = ke + (wk[k] * sinv) * (lap + g2);
+    }
+    if (out_grad) {   // d log psi / d x_d = sum_k w_k d_d log D_k  (complex: Re = grad log|psi|, Im = grad arg psi)
+        for (int d = 2 + lane; d < S.D; d += 64) {
+            Cx<T> acc(0, 0);
+            for (int k = 0; k < K; ++k) {
+                Cx<T> g(Tw[(size_t)(k * 2) * P + d], Tw[(size_t)(k * 2 + 1) * P + d]);
+                if (S.n_detch > 1) g = g + Cx<T>(Tw[tr_off1 + (size_t)(k * 2) * P + d], Tw[tr_off1 + (size_t)(k * 2 + 1) * P + d]);
+                acc = acc + (wk[k] * sinv) * g;
+            }
+            out_grad[((size_t)w * (S.D - 2) + (d - 2)) * 2] = acc.re;
+            out_grad[((size_t)w * (S.D - 2) + (d - 2)) * 2 + 1] = acc.im;
+        }
     }
     if (lane == 0) {
         if (out_ke) { out_ke[2 * w] = T(-0.5) * ke.re; out_ke[2 * w + 1] = T(-0.5) * ke.im; }

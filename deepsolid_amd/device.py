@@ -307,6 +307,19 @@ class DeviceSystem:
                                       _stream()), 'ds_logpsi')
         return la, ph
 
+    def logpsi_grad(self, params, x):
+        """-> (log|psi| (B,), grad (B, 3N) complex: Re = grad log|psi|, Im = grad arg psi)."""
+        x = self._check_x(x)
+        B = x.shape[0]
+        p = self.pack_params(params)
+        ws = self.workspace(B)
+        la = torch.empty(B, dtype=self.dtype, device=self.device)
+        gr = torch.empty(B, 3 * self.n, 2, dtype=self.dtype, device=self.device)
+        if B:
+            _lib.check(self.lib.ds_logpsi_grad(self.handle, _ptr(p), _ptr(x), B, _ptr(la), _ptr(None), _ptr(gr), _ptr(ws),
+                                               ws.numel(), _stream()), 'ds_logpsi_grad')
+        return la, torch.view_as_complex(gr)
+
     def orbitals(self, params, x):
         x = self._check_x(x)
         B = x.shape[0]

@@ -104,6 +104,13 @@ class NetworkApply:
             self._system = DeviceSystem.for_network(self.simulation_cell, self.klist, self.net_kw, self.dtype)
         return self._system
 
+    def value_and_grad(self, params, x):
+        """(log|psi|, d log|psi| / dx) for a batch: the `jax.vmap(jax.value_and_grad(f, argnums=1))` the
+        reference builds for importance sampling (qmc.py:324)."""
+        single = x.dim() == 1
+        la, g = self.system.logpsi_grad(params, x.reshape(1, -1) if single else x)
+        return (la[0], g.real[0]) if single else (la, g.real)
+
     def __call__(self, params, x):
         single = x.dim() == 1
         xb = x.reshape(1, -1) if single else x

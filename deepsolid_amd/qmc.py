@@ -4,13 +4,19 @@
 ``mcmc_step(params, data, key, width) -> (data, pmove)``.  The proposal + wrap
 (qmc.py:192-193) and the accept/select (qmc.py:217-222) are HIP kernels
 (``ds_mh_propose`` / ``ds_mh_accept``); the wavefunction call in between is the
-batched log-psi kernel chain.  ``key`` is a ``torch.Generator`` on the device
-(or an int seed): the Philox stream of torch replaces JAX's threefry, or explicit
-noise ``(normals, uniforms)`` can be supplied for reproducible tests.
+batched value-only log-psi kernel chain.  ``key`` is a ``torch.Generator`` on the
+device (or an int seed): torch's Philox stream replaces JAX's threefry; explicit
+noise ``(normals, uniforms)`` can be supplied instead for reproducible tests.
+
+All three samplers of the reference are available: all-electron Metropolis
+(``mh_update``, the default), one-electron moves (``mh_one_electron_update``) and
+drift-biased importance sampling (``importance_update``; the latter two are
+flagged "untested" in base_config.py:122-126).
 """
 import torch
 
 from . import constants
+from . import distance
 from .network import NetworkApply
 
 
@@ -22,50 +28,109 @@ def _generator(key, device):
     return g
 
 
+def _noise(key, x1, lp_1, normal, uniform, normal_shape=None):
+    if normal is None:
+        normal = torch.randn(normal_shape or x1.shape, dtype=x1.dtype, device=x1.device, generator=key)
+    if uniform is None:
+        uniform = torch.rand(lp_1.shape, dtype=lp_1.dtype, device=lp_1.device, generator=key)
+    return normal, uniform
+
+
+def limdrift(g, cutoff=1):
+    """Limit each electron's drift vector to magnitude `cutoff` (qmc.py:63-81)."""
+    shape = g.shape
+    g = g.reshape(-1, 3)
+    tot = torch.linalg.norm(g, dim=-1)
+    normalize = torch.clamp(tot, min=cutoff, max=float(tot.max()))
+    return (cutoff * g / normalize[:, None]).reshape(shape)
+
+
 def mh_update(params, f, x1, key, lp_1, num_accepts, latvec=None, stddev=0.02, atoms=None, i=0,
               normal=None, uniform=None):
     """One all-electron Metropolis step (qmc.py:153-224, symmetric branch).
     Returns (x_new, key, lp_new, num_accepts) like the reference."""
     del i, latvec                                  # the lattice lives in f.system
     if atoms is not None:
-        raise NotImplementedError('asymmetric proposals (atoms != None) are flagged untested in the reference '
-                                  '(base_config.py:122-126) and are not implemented on the device')
+        raise NotImplementedError('asymmetric proposals (atoms != None): process.py never passes atoms and the '
+                                  'reference flags the branch untested (base_config.py:119-121)')
     system = f.system
-    if normal is None:
-        normal = torch.randn(x1.shape, dtype=x1.dtype, device=x1.device, generator=key)
-    if uniform is None:
-        uniform = torch.rand(lp_1.shape, dtype=lp_1.dtype, device=lp_1.device, generator=key)
-    x2 = system.mh_propose(x1, normal, stddev)
+    normal, uniform = _noise(key, x1, lp_1, normal, uniform)
+    x2 = system.mh_propose(x1, normal, stddev)                                   # :192-193
+    lp_2 = 2.0 * f(params, x2)                                                   # :195
+    x_new, lp_new = x1.clone(), lp_1.clone()
+    system.mh_accept(x_new, lp_new, x2, lp_2.contiguous(), uniform.contiguous(), num_accepts)   # :217-222
+    return x_new, key, lp_new, num_accepts
+
+
+def mh_one_electron_update(params, f, x1, key, lp_1, num_accepts, latvec=None, stddev=0.02, atoms=None, i=0,
+                           normal=None, uniform=None):
+    """Metropolis step that moves electron i % N only (qmc.py:227-287)."""
+    del latvec
+    if atoms is not None:
+        raise NotImplementedError('Still need to work out reverse probabilities for asymmetric moves.')   # qmc.py:275
+    system = f.system
+    nelec = x1.shape[1] // 3
+    ii = i % nelec
+    normal, uniform = _noise(key, x1, lp_1, normal, uniform, normal_shape=(x1.shape[0], 3))
+    full = torch.zeros_like(x1)
+    full[:, 3 * ii:3 * ii + 3] = normal                                          # x1.at[:, ii].add(...)  :269
+    x2 = system.mh_propose(x1, full, stddev)                                     # + wrap of ALL electrons, :271
     lp_2 = 2.0 * f(params, x2)
     x_new, lp_new = x1.clone(), lp_1.clone()
     system.mh_accept(x_new, lp_new, x2, lp_2.contiguous(), uniform.contiguous(), num_accepts)
     return x_new, key, lp_new, num_accepts
 
 
+def importance_update(params, f, x1, key, lp_1, num_accepts, latvec, stddev=0.02, atoms=None, i=0,
+                      normal=None, uniform=None):
+    """Drift-biased all-electron move (qmc.py:83-150, symmetric branch).  `f(params, x)` must
+    return (log|psi|, grad log|psi|): ``NetworkApply.value_and_grad``."""
+    del i
+    if atoms is not None:
+        raise NotImplementedError('asymmetric importance sampling is not implemented')
+    system = f.__self__.system if hasattr(f, '__self__') else f.system
+    normal, uniform = _noise(key, x1, lp_1, normal, uniform)
+    _, grad = f(params, x1)                                                       # :111
+    grad = limdrift(grad)
+    gauss = stddev * normal
+    x2, _ = distance.enforce_pbc(latvec, x1 + gauss + stddev ** 2 * grad)         # :114-115
+    lpsi_2, new_grad = f(params, x2)                                              # :118
+    new_grad = limdrift(new_grad)
+    forward = (gauss ** 2).sum(-1)
+    backward = ((gauss + stddev ** 2 * (grad + new_grad)) ** 2).sum(-1)
+    lp_2 = 2 * lpsi_2 + 1 / (2 * stddev ** 2) * (forward - backward)              # :119-124
+    x_new, lp_new = x1.clone(), lp_1.clone()
+    system.mh_accept(x_new, lp_new, x2.contiguous(), lp_2.contiguous(), uniform.contiguous(), num_accepts)
+    return x_new, key, lp_new, num_accepts
+
+
 def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms=None,
                    importance_sampling=None, one_electron_moves=False):
-    if importance_sampling is not None:
-        if one_electron_moves:
-            raise ValueError('Importance sampling for one elec move is not implemented yet')
-        raise NotImplementedError('importance sampling is flagged untested in the reference and not implemented')
-    if one_electron_moves:
-        raise NotImplementedError('one-electron moves are flagged untested in the reference and not implemented')
     if not isinstance(batch_slog_network, NetworkApply) or batch_slog_network.method_name != 'eval_slogdet':
         raise TypeError("batch_slog_network must be the .apply of make_solid_fermi_net(method_name='eval_slogdet')")
-    f = batch_slog_network
-    del latvec                                     # equals f.system.cell.a (process.py:185)
+    if importance_sampling is not None:
+        if one_electron_moves:
+            raise ValueError('Importance sampling for one elec move is not implemented yet')      # qmc.py:321
+        if not isinstance(importance_sampling, NetworkApply):
+            raise TypeError('importance_sampling must be the .apply of make_solid_fermi_net (process.py:182)')
+        func, inner_fun = importance_sampling.value_and_grad, importance_update                   # qmc.py:324-325
+    else:
+        func = batch_slog_network
+        inner_fun = mh_one_electron_update if one_electron_moves else mh_update                  # qmc.py:327-333
 
     def mcmc_step(params, data, key, width):
-        """noise: `key` = torch.Generator / int seed, or a tuple (normals (steps,B,3N), uniforms (steps,B))."""
+        """noise: `key` = torch.Generator / int seed, or a tuple (normals (nsteps,B,...), uniforms (nsteps,B))."""
         explicit = isinstance(key, (tuple, list))
         gen = None if explicit else _generator(key, data.device)
-        logprob = 2.0 * f(params, data)                                           # qmc.py:357
+        nelec = data.shape[-1] // 3
+        nsteps = nelec * steps if one_electron_moves else steps                   # qmc.py:355-356
+        logprob = 2.0 * batch_slog_network(params, data)                          # :357
         num_accepts = torch.zeros(1, dtype=data.dtype, device=data.device)
-        for i in range(steps):                                                    # qmc.py:358
+        for i in range(nsteps):                                                   # :358
             nz, un = (key[0][i], key[1][i]) if explicit else (None, None)
-            data, _, logprob, num_accepts = mh_update(params, f, data, gen, logprob, num_accepts,
-                                                      stddev=width, atoms=atoms, normal=nz, uniform=un)
-        pmove = num_accepts[0] / (steps * batch_per_device)                       # qmc.py:360
-        pmove = constants.pmean_if_pmap(pmove)                                    # qmc.py:361
+            data, _, logprob, num_accepts = inner_fun(params, func, data, gen, logprob, num_accepts, latvec=latvec,
+                                                      stddev=width, atoms=atoms, i=i, normal=nz, uniform=un)
+        pmove = num_accepts[0] / (nsteps * batch_per_device)                      # :360
+        pmove = constants.pmean_if_pmap(pmove)                                    # :361
         return data, pmove
     return mcmc_step

@@ -61,11 +61,11 @@ typedef struct ds_system_desc {
     int32_t hidden_single[DS_MAX_LAYERS];
     int32_t hidden_double[DS_MAX_LAYERS];
     int32_t n_det;               /* determinants */
-    int32_t distance_type;       /* 0 = 'nu' (network.py:207); others rejected */
-    int32_t envelope_type;       /* 0 = 'isotropic' (network.py:335); others rejected */
-    int32_t full_det;            /* 0 (block-diagonal, base_config default); 1 rejected */
-    int32_t use_last_layer;      /* 0; 1 rejected */
-    int32_t bias_orbitals;       /* 0; 1 rejected */
+    int32_t distance_type;       /* 0 = 'nu' (network.py:207), 1 = 'tri' (network.py:227; isotropic envelope only) */
+    int32_t envelope_type;       /* 0 = 'isotropic' (network.py:335), 1 = 'diagonal' (:340), 2 = 'full' (:358) */
+    int32_t full_det;            /* 0 block-diagonal determinants per spin (base_config default), 1 dense N x N (network.py:558) */
+    int32_t use_last_layer;      /* 1: the orbital head takes the symmetric features of the last layer (network.py:535) */
+    int32_t bias_orbitals;       /* 1: orbital[s]['b'] is added to the orbital head (network.py:181-184) */
     const double* klist_up;      /* (n_up, 3) */
     const double* klist_dn;      /* (n_dn, 3) */
     /* Ewald tables */
@@ -90,10 +90,14 @@ typedef struct ds_system_desc {
  *   for l in layers:  W_loc_l  [(h1_in + nch*h2_in), h1_out]   rows: h_i | mean_j h2_ij (up) | (dn)
  *                     W_sh_l   [(nch*h1_in), h1_out]           rows: mean_up h | mean_dn h
  *                     b_l      [1, h1_out]
- *   for l in double layers: W2_l [h2_in, h2_out], b2_l [1, h2_out]
- *   for s in active spins:  W_orb_s [h1_last, 2*n_s*n_det]  (columns re/im interleaved in
- *                           groups of 4: see deepsolid_amd/network.py pack_params)
- *                           pi_s [A, n_s*n_det], sigma_s [A, n_s*n_det]
+ *   for l in double layers: W2_l [h2_in, h2_out], b2_l [1, h2_out]        (n_layers-1 of them, n_layers with use_last_layer)
+ *   for s in active spins:  W_orb_s [h1_last (+ nch*h2_last with use_last_layer), cols]  cols = 2*norb*n_det rounded up to 64,
+ *                             norb = n_s (N with full_det); Re/Im columns interleaved per 16-column tile, see
+ *                             deepsolid_amd/device.py::_orbital_column_map and csrc/ds_gemm.h::orb_col
+ *                           [W_sh_orb_s [nch*h1_last, cols]   only with use_last_layer]
+ *                           [b_orb_s [1, 2*norb*n_det]        only with bias_orbitals]
+ *                           pi_s [A, norb*n_det], sigma_s [A | 3A | 9A, norb*n_det] (isotropic | diagonal | full)
+ * Layer-0 rows are padded with zero rows to multiples of 4 (only 'tri', 7 features, needs it).
  * i.e. the rows of the reference's `single[l]['w']` (network.py:126-158) split
  * into the per-electron and the shared (spin-mean) part. */
 typedef struct ds_param_block {
@@ -117,6 +121,13 @@ int64_t ds_workspace_bytes(const ds_system* sys, int64_t B);
  * out_logabs (B,), out_phase (B,2) = (Re, Im) of the unit phase; either may be NULL. */
 int ds_logpsi(ds_system* sys, const void* params, const void* x, int64_t B,
               void* out_logabs, void* out_phase, void* ws, int64_t ws_bytes, void* stream);
+
+/* value and gradient of log psi w.r.t. the walker coordinates: what qmc.make_mcmc_step builds with
+ * jax.vmap(jax.value_and_grad(importance_sampling, argnums=1)) (qmc.py:324) for importance_update
+ * (qmc.py:83-150).  out_grad (B, 3N, 2): Re = grad log|psi|, Im = grad arg psi.  Uses the
+ * forward-Laplacian chain (the gradient is its trace stage); out_logabs / out_phase optional. */
+int ds_logpsi_grad(ds_system* sys, const void* params, const void* x, int64_t B,
+                   void* out_logabs, void* out_phase, void* out_grad, void* ws, int64_t ws_bytes, void* stream);
 
 /* network.eval_func method 'eval_mats' (network.py:601): out_up (B, n_det, n_up, n_up, 2),
  * out_dn (B, n_det, n_dn, n_dn, 2), complex as (Re, Im) pairs. */

@@ -51,3 +51,40 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
         pmove = num_accepts / (steps * batch_per_device)          # :360
         return data, pmove
     return mcmc_step
+
+
+# qmc.py:63-81
+def limdrift(g, cutoff=1):
+    shape = g.shape
+    g = g.reshape(-1, 3)
+    tot = torch.linalg.norm(g, dim=-1)
+    normalize = torch.clamp(tot, min=cutoff, max=float(tot.max()))
+    return (cutoff * g / normalize[:, None]).reshape(shape)
+
+
+# qmc.py:227-287 (symmetric branch)
+def mh_one_electron_update(params, f, x1, lp_1, num_accepts, latvec, stddev=0.02, i=0, normal=None, uniform=None):
+    n = x1.shape[0]
+    x = x1.reshape(n, -1, 3)
+    ii = i % x.shape[1]
+    x2 = x.clone()
+    x2[:, ii] = x2[:, ii] + stddev * normal                  # x1.at[:, ii].add(...)
+    x2, _ = distance.enforce_pbc(latvec, x2.reshape(n, -1))
+    lp_2 = 2.0 * f(params, x2)
+    cond = (lp_2 - lp_1) > torch.log(uniform)
+    return (torch.where(cond[..., None], x2, x1), torch.where(cond, lp_2, lp_1), num_accepts + cond.sum())
+
+
+# qmc.py:83-150 (symmetric branch); f(params, x) -> (log|psi| (B,), grad (B,3N))
+def importance_update(params, f, x1, lp_1, num_accepts, latvec, stddev=0.02, normal=None, uniform=None):
+    _, grad = f(params, x1)
+    grad = limdrift(grad)
+    gauss = stddev * normal
+    x2, _ = distance.enforce_pbc(latvec, x1 + gauss + stddev ** 2 * grad)
+    lpsi_2, new_grad = f(params, x2)
+    new_grad = limdrift(new_grad)
+    forward = (gauss ** 2).sum(-1)
+    backward = ((gauss + stddev ** 2 * (grad + new_grad)) ** 2).sum(-1)
+    lp_2 = 2 * lpsi_2 + 1 / (2 * stddev ** 2) * (forward - backward)
+    cond = (lp_2 - lp_1) > torch.log(uniform)
+    return (torch.where(cond[..., None], x2, x1), torch.where(cond, lp_2, lp_1), num_accepts + cond.sum())

@@ -125,3 +125,53 @@ def test_ragged_and_empty_batches():
         sysd.local_energy(dp, x[:, :-3])
     with pytest.raises(RuntimeError):
         sysd.local_energy(dp, x.cpu())
+
+
+@pytest.mark.parametrize('name', ['lih', 'bcc_li'])
+def test_gradient_one_electron_and_importance_moves_vs_oracle(name):
+    """ds_logpsi_grad vs autodiff, and the two 'untested' samplers of qmc.py (one-electron moves :227,
+    importance sampling :83) against the oracle's restatement on identical noise."""
+    from torch.func import grad as tgrad
+    from deepsolid_amd import qmc
+    from oracle import qmc as oqmc
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    (slog,) = nets(cell, klist, net_kw, 'eval_slogdet')
+    o_slog = oracle_net(cell, klist, net_kw, 'eval_slogdet')
+    cu = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device='cuda')
+    x1 = fx['pbc_x'][:3]
+    B, n3 = x1.shape
+    la, g = slog.apply.value_and_grad(dp, cu(x1))
+    g_ref = torch.stack([tgrad(lambda y: o_slog.apply(p_cpu, y))(tt(x1[b])) for b in range(B)])
+    np.testing.assert_allclose(la.cpu().numpy(), fx['logabs'][:3], atol=1e-9)
+    assert (g.cpu() - g_ref).abs().max() < 1e-8 * max(1.0, float(g_ref.abs().max()))
+    rng = np.random.default_rng(5)
+    f_o = lambda p, xs: torch.stack([o_slog.apply(p, x) for x in xs])
+    fg_o = lambda p, xs: (f_o(p, xs), torch.stack([tgrad(lambda y: o_slog.apply(p, y))(x) for x in xs]))
+    lp1 = 2.0 * f_o(p_cpu, tt(x1))
+    # one-electron move of electron 1
+    nz, un = rng.standard_normal((B, 3)), rng.uniform(size=B)
+    xo, lpo, na = oqmc.mh_one_electron_update(p_cpu, f_o, tt(x1), lp1, 0.0, cell.a, stddev=0.3, i=n3 // 3 + 1, normal=tt(nz), uniform=tt(un))
+    nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    xg, _, lpg, nacc = qmc.mh_one_electron_update(dp, slog.apply, cu(x1), None, cu(lp1), nacc, cell.a, stddev=0.3, i=n3 // 3 + 1,
+                                                  normal=cu(nz), uniform=cu(un))
+    np.testing.assert_allclose(xg.cpu().numpy(), xo.numpy(), atol=1e-10)
+    np.testing.assert_allclose(lpg.cpu().numpy(), lpo.numpy(), atol=1e-8)
+    assert float(nacc) == float(na)
+    # importance-sampled move
+    nz, un = rng.standard_normal((B, n3)), rng.uniform(size=B)
+    xo, lpo, na = oqmc.importance_update(p_cpu, fg_o, tt(x1), lp1, 0.0, cell.a, stddev=0.2, normal=tt(nz), uniform=tt(un))
+    nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    xg, _, lpg, nacc = qmc.importance_update(dp, slog.apply.value_and_grad, cu(x1), None, cu(lp1), nacc, cell.a, stddev=0.2,
+                                             normal=cu(nz), uniform=cu(un))
+    np.testing.assert_allclose(xg.cpu().numpy(), xo.numpy(), atol=1e-9)
+    np.testing.assert_allclose(lpg.cpu().numpy(), lpo.numpy(), atol=1e-7)
+    assert float(nacc) == float(na)
+    # the factories wire them up like qmc.py:319-333
+    s1 = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=1, one_electron_moves=True)
+    xa, pa = s1(dp, cu(x1), 3, 0.05)
+    assert xa.shape == (B, n3) and 0.0 <= float(pa) <= 1.0
+    s2 = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=2, importance_sampling=slog.apply)
+    xb, pb = s2(dp, cu(x1), 3, 0.05)
+    assert xb.shape == (B, n3) and 0.0 <= float(pb) <= 1.0
