@@ -477,8 +477,10 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void*
     T* MOUT = p; p += L.MOUT * ng;
     T* DETS = p; p += L.DETS * ng;
     auto blk = [&](int i) { return params + s->blocks[i].offset; };
-    hipLaunchKernelGGL((ds::k_features_val<T>), dim3((unsigned)ng), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]), blk(s->i_sg[0]),
-                       blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), G[0], MEAN[0], H2[0], Q);
+    hipLaunchKernelGGL((ds::k_features_val<T, 0>), dim3((unsigned)ng, ds::FV_SPLIT), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
+                       blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), G[0], MEAN[0], H2[0], Q);
+    hipLaunchKernelGGL((ds::k_features_val<T, 1>), dim3((unsigned)ng, ds::FV_SPLIT), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
+                       blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), G[0], MEAN[0], H2[0], Q);
     int gi = 0, hi = 0, mi = 0;
     const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
     for (int l = 0; l < S.n_layers; ++l) {

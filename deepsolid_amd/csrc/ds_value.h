@@ -63,17 +63,19 @@ __device__ __forceinline__ void tri_distance_val(const T r[3], const T* __restri
     }
 }
 
-// grid (groups), block 256.  Phase 1 writes the one-electron features and the pair features,
-// phase 2 (after a block barrier; same CU, so the rows just written are visible) the spin means and Q.
-template <typename T>
+// Two launches, grid (groups, FV_SPLIT), block 256: PHASE 0 writes the one-electron features and the pair
+// features, PHASE 1 (next launch, so the rows are visible) the spin means and Q.
+constexpr int FV_SPLIT = 16;
+template <typename T, int PHASE>
 __global__ void __launch_bounds__(256) k_features_val(SysDev<T> S, const T* __restrict__ x, long B, const T* __restrict__ env_pi0,
                                                       const T* __restrict__ env_sg0, const T* __restrict__ env_pi1,
                                                       const T* __restrict__ env_sg1, T* __restrict__ G, T* __restrict__ MEAN,
                                                       T* __restrict__ H2, T* __restrict__ Q) {
-    const int g = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int g = blockIdx.x, tid = blockIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * gridDim.y;
     const int N = S.N, A = S.A, NP = S.NP, K1 = S.h1[0], nf = S.nf;
     T* Gw = G + (size_t)g * N * S.ldk * PV;
     auto walker = [&](int c) { long wi = (long)g * PV + c; return wi < B ? wi : B - 1; };
+    if (PHASE == 0) {
     for (int idx = tid; idx < N * A * PV; idx += nt) {
         const int c = idx % PV, a = (idx / PV) % A, i = idx / (PV * A);
         const T* xp = x + (size_t)walker(c) * 3 * N + 3 * i;
@@ -104,7 +106,8 @@ __global__ void __launch_bounds__(256) k_features_val(SysDev<T> S, const T* __re
         T* Hw = H2 + (size_t)(g * (PV / 5) + c / 5) * S.h2[0] * 5 * NP;
         for (int k = 0; k < S.h2[0]; ++k) Hw[(size_t)(k * 5 + c % 5) * NP + q] = f[k];
     }
-    __syncthreads();
+    return;
+    }
     T* Mw = MEAN + (size_t)g * S.nch * K1 * PV;
     for (int idx = tid; idx < S.nch * K1 * PV; idx += nt) {
         const int c = idx % PV, k = (idx / PV) % K1, s = idx / (PV * K1);
@@ -147,18 +150,26 @@ __global__ void __launch_bounds__(256) k_features_val(SysDev<T> S, const T* __re
     }
 }
 
-// rows [row0, row0 + nch*K2) of G: mean over the partners j of spin s of h2[j][e] (values)
+// rows [row0, row0 + nch*K2) of G: mean over the partners j of spin s of h2[j][e] (values).
+// Eight lanes share one (k, walker) row of N contiguous partners and reduce with shuffles.
 template <typename T>
 __global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __restrict__ H2, int K2, T* __restrict__ G, int row0) {
     const int e = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, N = S.N, NP = S.NP;
+    const int part = tid & 7;
     T* Ge = G + ((size_t)(g * N + e) * S.ldk + row0) * PV;
-    for (int idx = tid; idx < S.nch * K2 * PV; idx += blockDim.x) {
-        const int c = idx % PV, k = (idx / PV) % K2, s = idx / (PV * K2);
-        const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
+    for (int r0 = 0; r0 < K2 * PV; r0 += 32) {
+        const int r = r0 + (tid >> 3);                       // K2 * PV is a multiple of 32
+        const int c = r % PV, k = r / PV;
         const T* hp = H2 + ((size_t)(g * (PV / 5) + c / 5) * K2 * 5 + (size_t)(k * 5 + c % 5)) * NP + (size_t)e * N;
-        T v = 0;
-        for (int j = j0; j < j0 + ns; ++j) v += hp[j];
-        Ge[idx] = v / T(ns);
+        T up = 0, dn = 0;
+        for (int j = part; j < N; j += 8) {
+            const T v = hp[j];
+            if (j < S.n_up) up += v; else dn += v;
+        }
+        up += __shfl_xor(up, 1); up += __shfl_xor(up, 2); up += __shfl_xor(up, 4);
+        dn += __shfl_xor(dn, 1); dn += __shfl_xor(dn, 2); dn += __shfl_xor(dn, 4);
+        if (part == 0) Ge[(size_t)k * PV + c] = up / T(S.n_up);
+        if (part == 1 && S.nch > 1) Ge[(size_t)(K2 + k) * PV + c] = dn / T(S.n_dn);
     }
 }
 
