@@ -115,8 +115,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ          # launched by torchrun: one process per GPU over RCCL
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', device_id=dev)
 
     from deepsolid_amd import network, systems, train
@@ -132,7 +134,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -150,13 +152,12 @@ def main():
     prof = sysd.profile_read()
     sysd.profile(False)
     log(f'{args.steps} steps in {dt:.3f} s; kernels: ' + ', '.join(f'{k}={v[0] / args.steps:.1f}ms' for k, v in prof.items()))
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     n_e = sum(cell.nelec)
@@ -201,7 +202,7 @@ def main():
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
