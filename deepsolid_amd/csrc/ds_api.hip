@@ -286,7 +286,7 @@ template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
 
 // workgroup size and grid.z of k_jet_gemm<NB>: at most 1024/NB threads (= its launch bound) per workgroup
 inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz) {
-    const int nw = Nout / (16 * NB), wmax = 1024 / NB / 64;
+    const int nw = Nout / (16 * NB), wmax = NB == 3 ? 4 : 1024 / NB / 64;
     const int wpb = nw < wmax ? nw : wmax;
     *block = dim3(wpb * 64);
     *gz = (unsigned)((nw + wpb - 1) / wpb);
@@ -413,6 +413,16 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             const int ch = S.mat_ch[sp];
             ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
                              S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr};
+            // 192 columns (n_s*K = 96) would give 3 waves of 64 columns per workgroup and leave SIMDs with a single wave;
+            // 48-column waves give 4 balanced waves (the MFMA pipe needs >= 2 waves per SIMD, profiles/r01_mfma_f64_probe.json)
+            if (NB == 4 && ST <= 5 && OC % 256 != 0 && OC % 192 == 0) {
+                dim3 b3; unsigned gz3;
+                gemm_geom(OC, 3, &b3, &gz3);
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, 3, (ST <= 5 ? ST : 1), 5>), dim3(ns, (unsigned)Bc, gz3), b3, 0, st,
+                                   c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
+                                   blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
+                                   (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
+            } else
             hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 5>), dim3(ns, (unsigned)Bc, gz), block, 0, st,
                                c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
                                blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,

@@ -393,12 +393,19 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
                 for (int e = 0; e < NMAX; ++e) yv[e] = Cx<T>(0, 0);
                 if (live) {
                     const T* mp = Mw + (size_t)(i * n * 2) * P + d;
-#pragma unroll 4
-                    for (int m = 0; m < n; ++m) {
-                        const Cx<T> dm(mp[(size_t)(2 * m) * P], mp[(size_t)(2 * m + 1) * P]);
+                    // all loads of this matrix row are issued before the first FMA (one exposed latency per row)
+                    T mre[NMAX], mim[NMAX];
 #pragma unroll
-                        for (int e = 0; e < NMAX; ++e)
-                            if (e < n) yv[e] = cx_fma(dm, minv[m * n + e], yv[e]);
+                    for (int m = 0; m < NMAX; ++m)
+                        if (m < n) { mre[m] = mp[(size_t)(2 * m) * P]; mim[m] = mp[(size_t)(2 * m + 1) * P]; }
+#pragma unroll
+                    for (int m = 0; m < NMAX; ++m) {
+                        if (m < n) {
+                            const Cx<T> dm(mre[m], mim[m]);
+#pragma unroll
+                            for (int e = 0; e < NMAX; ++e)
+                                if (e < n) yv[e] = cx_fma(dm, minv[m * n + e], yv[e]);
+                        }
                     }
                 }
 #pragma unroll
