@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,6 +67,11 @@ struct ds_system {
     // block indices
     std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_wsh_orb, i_borb, i_pi, i_sg;
     bool use_last = false;
+    // optional two-way chunk pipelining (DS_STREAMS=2): bandwidth-bound kernels of one chunk overlap the MFMA-bound
+    // kernels of the other; the side streams fork from / join the caller's stream with events
+    int n_streams = 1;
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[DS_PROF_KINDS];
@@ -607,8 +613,26 @@ template <typename T>
 int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B, void* out_ke, void* out_ewald, void* out_logabs,
                       void* out_phase, void* ws, int64_t ws_bytes, hipStream_t st) {
     const ds::SysDev<T>& S = dev<T>(s);
-    const int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T));
+    int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T));
     if (chunk < 1) return fail("workspace too small: %lld bytes < %zu per walker", (long long)ws_bytes, s->ws.per_walker * sizeof(T));
+    if (s->n_streams == 2 && chunk >= 2 && B > chunk / 2 && !s->prof_on) {
+        // two half-size workspaces, chunks alternate between two side streams
+        const int64_t half = chunk / 2;
+        char* wsp[2] = {(char*)ws, (char*)ws + (size_t)half * s->ws.per_walker * sizeof(T)};
+        HIP_OK(hipEventRecord(s->ev_fork, st));
+        for (int k = 0; k < 2; ++k) HIP_OK(hipStreamWaitEvent(s->side[k], s->ev_fork, 0));
+        int k = 0;
+        for (int64_t b0 = 0; b0 < B; b0 += half, k ^= 1) {
+            const int64_t Bc = std::min(half, B - b0);
+            int rc = run_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, wsp[k], s->side[k], out_ke ? (T*)out_ke + 2 * b0 : nullptr,
+                                  out_logabs ? (T*)out_logabs + b0 : nullptr, out_phase ? (T*)out_phase + 2 * b0 : nullptr, nullptr);
+            if (rc) return rc;
+        }
+        for (int j = 0; j < 2; ++j) {
+            HIP_OK(hipEventRecord(s->ev_join[j], s->side[j]));
+            HIP_OK(hipStreamWaitEvent(st, s->ev_join[j], 0));
+        }
+    } else
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t Bc = std::min(chunk, B - b0);
         const T* xb = (const T*)x + b0 * 3 * S.N;
@@ -690,12 +714,25 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     relocate<double>(s->sd, (const double*)s->blob64);
     relocate<float>(s->sf, (const float*)s->blob32);
     build_layouts(s);
+    if (const char* e = getenv("DS_STREAMS")) s->n_streams = atoi(e) == 2 ? 2 : 1;
+    if (s->n_streams == 2) {
+        for (int k = 0; k < 2; ++k) {
+            (void)hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking);
+            (void)hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming);
+        }
+        (void)hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+    }
     *out = s;
     return 0;
 }
 
 void ds_system_destroy(ds_system* s) {
     if (!s) return;
+    for (int k = 0; k < 2; ++k) {
+        if (s->side[k]) (void)hipStreamDestroy(s->side[k]);
+        if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->blob64) hipFree(s->blob64);
     if (s->blob32) hipFree(s->blob32);
     delete s;
@@ -713,8 +750,13 @@ int ds_param_layout(const ds_system* s, ds_param_block* blocks, int max_blocks) 
 int64_t ds_workspace_bytes(const ds_system* s, int64_t B) {
     if (!s) return -1;
     const int64_t esz = s->dtype == 0 ? 8 : 4;
-    const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 1024);
-    const int64_t groups = std::min<int64_t>((std::max<int64_t>(B, 1) + ds::PV - 1) / ds::PV, 64);
+    // walkers are processed in chunks: at most 1024 per chunk and at most ~24 GiB of scratch (large cells need
+    // hundreds of MB per walker: 96 electrons f32 = 0.2 GB)
+    const int64_t budget = (int64_t)24 << 30;
+    int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 1024);
+    chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, budget / ((int64_t)s->ws.per_walker * esz)));
+    int64_t groups = std::min<int64_t>((std::max<int64_t>(B, 1) + ds::PV - 1) / ds::PV, 64);
+    groups = std::max<int64_t>(1, std::min<int64_t>(groups, budget / ((int64_t)s->wsv.per_walker * esz)));
     return std::max((int64_t)s->ws.per_walker * esz * chunk, (int64_t)s->wsv.per_walker * esz * groups) + 256;
 }
 

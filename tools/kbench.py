@@ -18,6 +18,7 @@ ap.add_argument('--batch', type=int, default=1024)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--check', type=int, default=2)
 ap.add_argument('--dtype', default='f64')
+ap.add_argument('--noprof', action='store_true')
 args = ap.parse_args()
 dtype = torch.float64 if args.dtype == 'f64' else torch.float32
 cell, klist = systems.build(args.system)
@@ -30,7 +31,7 @@ el = hamiltonian.local_energy_seperate(net.apply, cell)
 ke, ew = el(params, x)
 torch.cuda.synchronize()
 sysd = net.apply.system
-sysd.profile(True)
+sysd.profile(not args.noprof)
 t0 = time.perf_counter()
 for _ in range(args.steps):
     ke, ew = el(params, x)
