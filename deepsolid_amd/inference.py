@@ -1,0 +1,89 @@
+"""Energy evaluation of a fixed wavefunction: the `optimizer='none'` branch of the reference driver
+(reference DeepSolid/process.py:256-374), i.e. burn-in, then per iteration
+``mcmc_step -> total_energy -> one CSV row -> MCMC width adaptation``.
+
+This is SURVEY.md section 8 row f1: the smallest step from "kernel" to "usable VMC energy of a trained
+wavefunction".  Everything numeric runs in the HIP chain; this module is host bookkeeping only.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import qmc, train
+
+TRAIN_SCHEMA = ['step', 'energy', 'variance', 'pmove', 'imaginary', 'kinetic', 'ewald']   # process.py:276
+
+
+class Writer:
+    """CSV writer with the reference's file layout (utils/writers.py:27-91, iteration_key=None)."""
+
+    def __init__(self, name, schema, directory='logs/'):
+        self._schema = list(schema)
+        os.makedirs(directory, exist_ok=True)
+        self._filename = os.path.join(directory, name + '.csv')
+
+    def __enter__(self):
+        header = not os.path.exists(self._filename)
+        self._file = open(self._filename, 'a+')
+        if header:
+            self._file.write(','.join(self._schema) + '\n')
+        return self
+
+    def write(self, t, **data):
+        for key in data:
+            if key not in self._schema:
+                raise ValueError('Not a recognized key for writer: %s' % key)
+        self._file.write(','.join(str(data.get(key, '')) for key in self._schema) + '\n')
+
+    def __exit__(self, *exc):
+        self._file.flush()
+        self._file.close()
+
+
+def run_inference(slog_net, logdet_net, params, data, simulation_cell, iterations, key=0, move_width=0.02,
+                  mcmc_steps=20, burn_in=100, adapt_frequency=100, stats_frequency=1, save_path=None,
+                  stats_file_name='train_stats', laplacian_mode='for', partition_number=3):
+    """Returns (data, mcmc_width, rows).  `slog_net` / `logdet_net` are the objects returned by
+    ``make_solid_fermi_net(method_name='eval_slogdet' | 'eval_logdet')``; `data` is (B, 3N) on the device.
+    Energies are reported per primitive cell like process.py:330-334 (divided by ``simulation_cell.scale``)."""
+    gen = key if isinstance(key, torch.Generator) else torch.Generator(device=data.device).manual_seed(int(key))
+    batch = data.shape[0]
+    mcmc_step = qmc.make_mcmc_step(slog_net.apply, batch, latvec=simulation_cell.a, steps=mcmc_steps)
+    total_energy = train.make_loss(logdet_net.apply, None, simulation_cell, mode=laplacian_mode,
+                                   partition_number=partition_number)
+    width = float(move_width)
+    for _ in range(burn_in):                                             # process.py:256-261
+        data, _ = mcmc_step(params, data, gen, width)
+    scale = float(getattr(simulation_cell, 'scale', 1))
+    pmoves = np.zeros(adapt_frequency)
+    rows = []
+    writer = Writer(stats_file_name, TRAIN_SCHEMA, save_path) if save_path else None
+    if writer:
+        writer.__enter__()
+    try:
+        for t in range(iterations):
+            data, pmove = mcmc_step(params, data, gen, width)            # process.py:320
+            loss, aux = total_energy(params, data)                       # :321
+            row = {'step': t,
+                   'energy': float(loss) / scale,                        # :330-334
+                   'variance': float(aux.variance) / scale ** 2,
+                   'pmove': float(pmove),
+                   'imaginary': float(aux.imaginary) / scale,
+                   'kinetic': complex(aux.kinetic.mean().item()) / scale,
+                   'ewald': float(aux.ewald.mean()) / scale}
+            if t % stats_frequency == 0:
+                rows.append(row)
+                if writer:
+                    writer.write(t, **row)
+            if t > 0 and t % adapt_frequency == 0:                       # :368-373
+                if np.mean(pmoves) > 0.55:
+                    width *= 1.1
+                if np.mean(pmoves) < 0.5:
+                    width /= 1.1
+                pmoves[:] = 0
+            pmoves[t % adapt_frequency] = row['pmove']
+    finally:
+        if writer:
+            writer.__exit__(None, None, None)
+    return data, width, rows

@@ -175,3 +175,22 @@ def test_gradient_one_electron_and_importance_moves_vs_oracle(name):
     s2 = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=2, importance_sampling=slog.apply)
     xb, pb = s2(dp, cu(x1), 3, 0.05)
     assert xb.shape == (B, n3) and 0.0 <= float(pb) <= 1.0
+
+
+def test_inference_loop_writes_reference_csv(tmp_path):
+    """optimizer='none' loop of process.py:289-374 on LiH: CSV schema, width adaptation, finite energies."""
+    from deepsolid_amd import inference, init_guess
+    fx, cell, klist, net_kw, params = load_case('lih')
+    dp = dev_params(params)
+    slog, ld = nets(cell, klist, net_kw, 'eval_slogdet', 'eval_logdet')
+    x0 = torch.as_tensor(init_guess.init_electrons(3, cell, cell.a, cell.nelec, 64, init_width=0.8), device='cuda')
+    data, width, rows = inference.run_inference(slog, ld, dp, x0, cell, iterations=5, key=11, move_width=0.3, mcmc_steps=4,
+                                                burn_in=3, adapt_frequency=2, save_path=str(tmp_path))
+    assert len(rows) == 5 and data.shape == x0.shape
+    assert all(np.isfinite(r['energy']) and 0 <= r['pmove'] <= 1 for r in rows)
+    text = (tmp_path / 'train_stats.csv').read_text().splitlines()
+    assert text[0] == 'step,energy,variance,pmove,imaginary,kinetic,ewald' and len(text) == 6
+    assert width != 0.3                      # adapted at t = 2 and t = 4
+    data2, width2, rows2 = inference.run_inference(slog, ld, dp, x0, cell, iterations=5, key=11, move_width=0.3, mcmc_steps=4,
+                                                   burn_in=3, adapt_frequency=2)
+    assert torch.equal(data, data2) and rows[-1]['energy'] == rows2[-1]['energy']      # reproducible from the seed

@@ -92,3 +92,24 @@ print('rank', r, 'ok')
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('ok') == 2
+
+
+def test_poscar_reader_and_init_electrons(tmp_path):
+    """reference config/poscar/bcc_li.vasp content (data fixture) -> 2-atom conventional bcc cell."""
+    from deepsolid_amd import init_guess, supercell
+    poscar = tmp_path / 'bcc_li.vasp'
+    poscar.write_text("Li2\n1.0\n 3.4268178940 0.0 0.0\n 0.0 3.4268178940 0.0\n 0.0 0.0 3.4268178940\n Li\n 2\nCartesian\n"
+                      " 0.0 0.0 0.0\n 1.713408947 1.713408947 1.713408947\n")
+    cell = init_guess.read_poscar(str(poscar))
+    a0 = 3.4268178940 / 0.52917721067
+    np.testing.assert_allclose(cell.a, np.eye(3) * a0, atol=1e-9)
+    np.testing.assert_allclose(cell.atom_coords()[1], np.full(3, 1.713408947 / 0.52917721067), atol=1e-9)
+    assert cell.nelec == (3, 3)
+    sim = supercell.get_supercell(cell, np.eye(3))
+    x = init_guess.init_electrons(7, sim, sim.a, sim.nelec, batch_size=16, init_width=0.8)
+    assert x.shape == (16, 18)
+    frac = x.reshape(16, 6, 3) @ np.linalg.inv(sim.a)
+    assert frac.min() >= 0 and frac.max() < 1
+    # spin-polarised request: one spin flipped somewhere
+    x2 = init_guess.init_electrons(7, sim, sim.a, (4, 2), batch_size=4)
+    assert x2.shape == (4, 18)
