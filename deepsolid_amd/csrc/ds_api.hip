@@ -298,7 +298,7 @@ inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz) {
     *gz = (unsigned)((nw + wpb - 1) / wpb);
 }
 
-enum Stop { STOP_NONE = 0, STOP_G0, STOP_G1, STOP_G2, STOP_G3, STOP_H2_0, STOP_H2_1, STOP_H2_2, STOP_MEAN0, STOP_MEAN1, STOP_Q,
+enum Stop { STOP_NONE = 0, STOP_G0, STOP_G1, STOP_G2, STOP_G3, STOP_H2_0, STOP_H2_1, STOP_H2_2, STOP_MEAN0, STOP_Q,
             STOP_MOUT, STOP_MINV, STOP_DETS, STOP_TR };
 
 template <typename T> struct DumpReq { int stop; T* out; int64_t cap; int64_t written; };
@@ -871,7 +871,7 @@ int64_t ds_debug_stage(ds_system* s, const void* params, const void* x, int64_t 
     if (!s || !params || !x || !stage || !out || !ws) { fail("null argument"); return -1; }
     static const struct { const char* name; int stop; } names[] = {
         {"g0", STOP_G0}, {"g1", STOP_G1}, {"g2", STOP_G2}, {"g3", STOP_G3}, {"h2_0", STOP_H2_0}, {"h2_1", STOP_H2_1},
-        {"h2_2", STOP_H2_2}, {"mean0", STOP_MEAN0}, {"mean1", STOP_MEAN1}, {"q", STOP_Q}, {"mout", STOP_MOUT},
+        {"h2_2", STOP_H2_2}, {"mean0", STOP_MEAN0}, {"q", STOP_Q}, {"mout", STOP_MOUT},
         {"minv", STOP_MINV}, {"dets", STOP_DETS}, {"tr", STOP_TR}};
     int stop = -1;
     for (auto& n : names)

@@ -3,7 +3,6 @@
 //   k_jet_gemm          Z[tile][n][slot] = sum_k W[k][n] * X[tile][k][slot]      (fp64/fp32 MFMA)
 //                       with optional fused epilogues: one-electron layer (tanh chain rule, residual)
 //                       or orbital head (envelope x phase product rule)
-//   k_spin_mean         spin means of the new one-electron stream
 //   k_shared_term       the per-walker spin-mean term of a hidden layer, means formed on the fly
 //
 // The GEMM main loop needs only its accumulators and two k-steps of operands in registers, which
@@ -297,20 +296,6 @@ k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, i
 #pragma unroll
             for (int s = 0; s < ST; ++s) Sp[(size_t)n * P + 16 * s + lr] = acc[a][s][r];
         }
-}
-
-// spin means of the new one-electron stream:  MEAN[w][sp][n][slot] = mean_{i in sp} G[w][i][n][slot]
-template <typename T>
-__global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restrict__ G, T* __restrict__ MEANout, int Nout, int P) {
-    const int w = blockIdx.z, sp = blockIdx.y;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (size_t)Nout * P) return;
-    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn;
-    const T* g = G + ((size_t)(w * S.N + i0) * S.ldk) * P + e;
-    T acc = 0;
-#pragma unroll 4
-    for (int i = 0; i < ns; ++i) acc += g[(size_t)i * S.ldk * P];
-    MEANout[(((size_t)w * S.nch + sp) * Nout) * P + e] = acc / T(ns);
 }
 
 }  // namespace ds

@@ -650,14 +650,6 @@ template <typename T> __global__ void k_sum3(const T* __restrict__ t, long n, T*
     if (w < n) out[w] = t[3 * w] + t[3 * w + 1] + t[3 * w + 2];
 }
 
-// value slot of MOUT -> dense (B, K, n, n, 2) complex orbital matrices (network.py:601 'eval_mats')
-template <typename T>
-__global__ void k_gather_slot0(const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off, size_t per, int P,
-                               T* __restrict__ out) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
-    if (idx < per) out[w * per + idx] = MOUT[w * mout_stride + mout_off + idx * P];
-}
-
 // HBM counter calibration: a plain 8-byte-per-lane copy (the access width of every jet tensor load / store)
 __global__ void k_calib_copy(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];

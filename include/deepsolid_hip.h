@@ -176,15 +176,13 @@ int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_
 #define DS_PROF_TWO_LAYER 2
 #define DS_PROF_SINGLE_FIRST 3   /* k_jet_gemm of one-electron layer 0 (K = 4A + 8) */
 #define DS_PROF_SINGLE_HIDDEN 4  /* k_jet_gemm of the hidden one-electron layers (K = 256 + 64): the dominant kernel */
-#define DS_PROF_ORBITAL 5        /* k_jet_gemm of the orbital head */
+#define DS_PROF_ORBITAL 5        /* k_jet_gemm<.,5> of the orbital head (fused envelope x phase epilogue) */
 #define DS_PROF_DET_INVERSE 6
 #define DS_PROF_DET_TRACE 7
 #define DS_PROF_COMBINE 8
 #define DS_PROF_EWALD 9
-#define DS_PROF_LAYER_EPILOGUE 10  /* k_spin_mean */
-#define DS_PROF_ORBITAL_EPILOGUE 11
-#define DS_PROF_SHARED_TERM 12    /* k_jet_gemm<.,0> of the per-walker spin-mean term S = W_sh^T MEAN */
-#define DS_PROF_KINDS 13
+#define DS_PROF_SHARED_TERM 10    /* per-walker spin-mean term S = W_sh^T mean_i h_i (k_shared_term; layer 0: k_jet_gemm<.,0>) */
+#define DS_PROF_KINDS 11
 int ds_profile_enable(ds_system* sys, int on);
 int ds_profile_read(ds_system* sys, double* ms_total, int64_t* launches);
 
