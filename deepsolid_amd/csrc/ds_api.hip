@@ -443,7 +443,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
         ProfScope ps(s, DS_PROF_DET_INVERSE, st);
         hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp,
-                           c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp], S.P, 1);
+                           c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp], S.P, 16, 1);   // value = slot 0 of slot tile 0
     }
     if (stop == STOP_MINV) return copy_out(dr, c.MINV, L.MINV * Bc, st);
     for (int sp = 0; sp < S.n_detch; ++sp) {
@@ -458,6 +458,16 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                            L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,        \
                            L.dets_off[sp]);                                                                                    \
     } while (0)
+        // matrix-core version when the real expansion (2n) is a whole number of k-steps and one slot tile of Y fits LDS
+        const size_t ybytes = (size_t)n * 2 * n * 16 * sizeof(T) + 256 * sizeof(ds::Cx<T>);
+        const int nt = (2 * n + 15) / 16;
+        if ((2 * n) % 4 == 0 && ybytes <= 150 * 1024 && nt <= 4 && !getenv("DS_DET_VALU")) {
+#define DS_TRM(NTV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV>), dim3(S.K, (unsigned)Bc), dim3(256), ybytes, st, S, c.MOUT, L.MOUT,  \
+                                       L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
+                                       L.dets_off[sp])
+            if (nt == 1) DS_TRM(1); else if (nt == 2) DS_TRM(2); else if (nt == 3) DS_TRM(3); else DS_TRM(4);
+#undef DS_TRM
+        } else
         if (n <= 16) DS_TRACE(16, 16);
         else if (n <= 32) DS_TRACE(32, 8);
         else if (n <= 64) DS_TRACE(64, 2);      // LDS: (1 + SP) n^2 complex must stay below 160 KiB
@@ -559,7 +569,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void*
             const int n = S.det_n[sp];
             size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
             hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, MOUT, L.MOUT, L.mout_off[sp], sp,
-                               (T*)nullptr, (size_t)0, (size_t)0, DETS, dstride, s->ws.dets_off[sp], PV, PV);
+                               (T*)nullptr, (size_t)0, (size_t)0, DETS, dstride, s->ws.dets_off[sp], PV, PV, PV);
         }
         hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, (const T*)nullptr, (size_t)0, (size_t)0, DETS, dstride,
                            s->ws.dets_off[1], (T*)nullptr, out_logabs, out_phase, (T*)nullptr);

@@ -23,7 +23,7 @@ template <typename T> __device__ __forceinline__ int orb_col(int p, int part) {
 // fused orbital epilogue arguments (EPI = 5): M = phi * q with the product rule on the jets
 template <typename T> struct OrbEpi {
     const T* Q;            // [walker][electron][nparam_max][10]
-    T* MOUT;               // [walker][spin][det][elec][orb][re,im][P]
+    T* MOUT;               // [walker][channel][det][slot tile][elec][orb][re,im][16]
     size_t mout_stride, mout_off;   // walker stride and offset of this spin's determinant channel
     int N, i0, nparam, nparam_max;
     int norb, n, row0;              // orbitals per det, matrix size, first matrix row of this spin's electrons
@@ -167,7 +167,9 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
                 if (valid) {
                     const int kdet = p / oe.norb, m = p % oe.norb;
-                    T* mo = Mw + (((size_t)(kdet * oe.n + oe.row0 + tile) * oe.n + m) * 2) * P + lr;
+                    // MOUT is slot-tile major: [det][slot tile][elec][orb][re,im][16]
+                    T* mo = Mw + (size_t)kdet * oe.n * oe.n * 2 * P + (((size_t)(oe.row0 + tile) * oe.n + m) * 2) * 16 + lr;
+                    const size_t tstride = (size_t)oe.n * oe.n * 2 * 16;
 #pragma unroll
                     for (int s = 0; s < ST; ++s) {
                         const int slot = 16 * s + lr;
@@ -176,8 +178,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                         else if (slot == so) v = v + f0 * qg0;
                         else if (slot == so + 1) v = v + f0 * qg1;
                         else if (slot == so + 2) v = v + f0 * qg2;
-                        mo[16 * s] = v.re;
-                        mo[P + 16 * s] = v.im;
+                        mo[s * tstride] = v.re;
+                        mo[s * tstride + 16] = v.im;
                     }
                 }
             }

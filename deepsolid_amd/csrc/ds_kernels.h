@@ -9,7 +9,8 @@
 //   H2   [walker][k2][5][NP]              two-electron stream, 5 = (value, d/dr_x, d/dr_y, d/dr_z, Laplacian)
 //                                         h2[j][e] as a function of r = x_j - x_e, stored at pair = e*N + j;
 //                                         NP = roundup16(N*N)
-//   MOUT [walker][spin][det k][elec i][orb m][re/im][P]   orbital matrices with all slots
+//   MOUT [walker][channel][det k][slot tile][elec i][orb m][re/im][16]   orbital matrices with all slots, slot-tile
+//                                         major so that the determinant kernels stream one tile contiguously
 //
 // Every dense contraction is computed TRANSPOSED, C[n][slot] = sum_k W[k][n] * X[k][slot], so that
 // the MFMA A operand is a row of the weight matrix (n contiguous), the B operand is a row of the
@@ -283,9 +284,11 @@ template <typename T>
 __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                     int sp, T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                     T* __restrict__ DETS, size_t dets_stride, size_t dets_off, int P,
-                                                    int cols_per_group) {
-    // forward-Laplacian chain: P = S.P, cols_per_group = 1 (value = slot 0 of walker w);
-    // value chain: P = PV, cols_per_group = PV (value of walker w = column w % PV of group w / PV)
+                                                    int es, int cols_per_group) {
+    // P = slots per matrix element (sets the per-determinant block size), es = stride between consecutive
+    // (elec, orb, re/im) entries of the value:
+    //   forward-Laplacian chain: P = S.P, es = 16 (slot 0 of slot tile 0), cols_per_group = 1;
+    //   value chain: P = es = PV, cols_per_group = PV (walker w = column w % PV of group w / PV)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Cx<T>* aug = reinterpret_cast<Cx<T>*>(smem_raw);   // [n][2n]
     const int kdet = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
@@ -294,7 +297,7 @@ __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __rest
     const T* Mw = MOUT + (size_t)(w / cols_per_group) * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P + w % cols_per_group;
     for (int idx = lane; idx < n * n; idx += 64) {
         const int r = idx / n, c = idx % n;
-        aug[r * n2 + c] = Cx<T>(Mw[(size_t)(idx * 2) * P], Mw[(size_t)(idx * 2 + 1) * P]);
+        aug[r * n2 + c] = Cx<T>(Mw[(size_t)(idx * 2) * es], Mw[(size_t)(idx * 2 + 1) * es]);
         aug[r * n2 + n + c] = Cx<T>(r == c ? T(1) : T(0), T(0));
     }
     __syncthreads();
@@ -392,12 +395,12 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
 #pragma unroll
                 for (int e = 0; e < NMAX; ++e) yv[e] = Cx<T>(0, 0);
                 if (live) {
-                    const T* mp = Mw + (size_t)(i * n * 2) * P + d;
+                    const T* mp = Mw + ((size_t)(d >> 4) * n * n * 2 + (size_t)i * n * 2) * 16 + (d & 15);   // slot-tile major MOUT
                     // all loads of this matrix row are issued before the first FMA (one exposed latency per row)
                     T mre[NMAX], mim[NMAX];
 #pragma unroll
                     for (int m = 0; m < NMAX; ++m)
-                        if (m < n) { mre[m] = mp[(size_t)(2 * m) * P]; mim[m] = mp[(size_t)(2 * m + 1) * P]; }
+                        if (m < n) { mre[m] = mp[(size_t)(2 * m) * 16]; mim[m] = mp[(size_t)(2 * m + 1) * 16]; }
 #pragma unroll
                     for (int m = 0; m < NMAX; ++m) {
                         if (m < n) {
@@ -439,6 +442,103 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
     if (tid == 0) {
         Cx<T> t(0, 0);
         for (int g = 0; g < nthr; ++g) t = t + red[g];
+        T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
+        dw[2] = t.re;
+        dw[3] = t.im;
+    }
+}
+
+// =====================================================================================
+// 5b'. the same traces on the matrix cores (used when 2n is a multiple of 4 and the Y chunk fits LDS):
+//     Y_d[i][e] = sum_m d_dM[i][m] Minv[m][e] is, in real arithmetic, C[(e,ri')][slot] = sum_{(m,ri)} A * X with
+//     X = the MOUT rows of electron i ([m][re,im][P], already k-major / slot-contiguous) and A the 2n x 2n real
+//     expansion of Minv^T, built on the fly from MINV.  One workgroup per (walker, channel, det) walks the slot
+//     tiles; the four waves split the electrons, park Y of one slot tile in LDS, then all threads form
+//     tr Y_d and sum_{i,e} Y_d[i][e] Y_d[e][i] with conflict-free LDS reads.
+// =====================================================================================
+template <typename T, int NT>
+__global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
+                                                        int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
+                                                        T* __restrict__ TR, size_t tr_stride, size_t tr_off,
+                                                        T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+    typedef typename Acc4<T>::type acc_t;
+    constexpr int KSMAX = 4 * NT;                         // 2n <= 16 NT  ->  2n / 4 <= 4 NT k-steps
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int P = S.P, n = S.det_n[ch], n2 = 2 * n, nks = n2 / 4;
+    T* Y = reinterpret_cast<T*>(smem_raw);               // [n][2n][16]
+    Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)n * n2 * 16);   // [256]
+    const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
+    const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
+    T* Tw = TR + (size_t)w * tr_stride + tr_off + (size_t)kdet * 2 * P;
+    // A fragments (slot independent): A[n' = (e, ri')][k' = (m, ri)]
+    T af[NT][KSMAX];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int np = 16 * nt + lr, kp = 4 * ks + lq;
+            T v = 0;
+            if (np < n2 && ks < nks) {
+                const int e = np >> 1, rip = np & 1, m = kp >> 1, ri = kp & 1;
+                const T re = Iw[(m * n + e) * 2], im = Iw[(m * n + e) * 2 + 1];
+                v = (ri == rip) ? re : (rip == 0 ? -im : im);
+            }
+            af[nt][ks] = v;
+        }
+    Cx<T> y2(0, 0);
+    const int d = tid & 15, g = tid >> 4;
+    for (int st = 0; st < P / 16; ++st) {
+        for (int i = wave; i < n; i += 4) {
+            acc_t acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = acc_t{0, 0, 0, 0};
+            const T* xp = Mw + ((size_t)st * n * n2 + (size_t)i * n2 + lq) * 16 + lr;      // contiguous n*2n*16 chunk per slot tile
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks) {
+                if (ks < nks) {
+                    const T b = xp[(size_t)(4 * ks) * 16];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(af[nt][ks], b, acc[nt]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int np = 16 * nt + acc_row<T>(lane, r);
+                    if (np < n2) Y[((size_t)i * n2 + np) * 16 + lr] = acc[nt][r];
+                }
+        }
+        __syncthreads();
+        const int slot = 16 * st + d;
+        const bool live = slot >= 1 && slot < S.D;
+        Cx<T> trc(0, 0);
+        for (int pi = g; pi < n * n; pi += 16) {
+            const int i = pi / n, e = pi % n;
+            const Cx<T> yie(Y[((size_t)i * n2 + 2 * e) * 16 + d], Y[((size_t)i * n2 + 2 * e + 1) * 16 + d]);
+            if (i == e) trc = trc + yie;
+            if (slot >= 2) {
+                const Cx<T> yei(Y[((size_t)e * n2 + 2 * i) * 16 + d], Y[((size_t)e * n2 + 2 * i + 1) * 16 + d]);
+                y2 = cx_fma(yie, yei, y2);
+            }
+        }
+        red[tid] = trc;
+        __syncthreads();
+        if (g == 0 && live) {
+            Cx<T> t(0, 0);
+            for (int q = 0; q < 16; ++q) t = t + red[q * 16 + d];
+            Tw[slot] = t.re;
+            Tw[P + slot] = t.im;
+        }
+        __syncthreads();
+    }
+    red[tid] = y2;
+    __syncthreads();
+    if (tid == 0) {
+        Cx<T> t(0, 0);
+        for (int q = 0; q < 256; ++q) t = t + red[q];
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
         dw[2] = t.re;
         dw[3] = t.im;

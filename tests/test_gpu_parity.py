@@ -137,7 +137,9 @@ def test_stages_vs_forward_laplacian_oracle(name):
         for s, ns in enumerate(sysd.nelec):
             if ns == 0:
                 continue
-            m = mo[b, off:off + sysd.n_det * ns * ns * 2 * P].reshape(sysd.n_det, ns, ns, 2, P)
+            # slot-tile major: [det][slot tile][elec][orb][re,im][16] -> [det][elec][orb][re,im][P]
+            m = mo[b, off:off + sysd.n_det * ns * ns * 2 * P].reshape(sysd.n_det, P // 16, ns, ns, 2, 16)
+            m = m.transpose(0, 2, 3, 4, 1, 5).reshape(sysd.n_det, ns, ns, 2, P)
             got = m[..., 0, :D] + 1j * m[..., 1, :D]
             ref = st[b]['mats'][s].numpy()
             assert rel_err(got, ref) < tol, f'mats_{s}'
