@@ -103,7 +103,9 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--system', default='bcc_li')
-    ap.add_argument('--batch', type=int, default=4096, help='walkers per GPU')
+    ap.add_argument('--batch', type=int, default=4096, help='walkers per GPU (weak) or in total (strong)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: every rank keeps --batch walkers (default); strong: --batch walkers are split across the ranks')
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -111,6 +113,8 @@ def main():
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.scaling == 'strong':
+        args.batch = max(1, args.batch // world)
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -173,7 +177,7 @@ def main():
     out = {
         'metric': 'local-energy evals/sec', 'value': world * args.batch * args.steps / dt,
         'unit': 'local-energy evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': f'{args.system} {n_e} e- ({cell.nelec[0]},{cell.nelec[1]}), total_energy primal '
                                f'(E_kin forward-Laplacian + Ewald), default detnet ((256,32),)*3, 8 dets',
