@@ -293,7 +293,11 @@ template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
 // workgroup size and grid.z of k_jet_gemm<NB>: at most 1024/NB threads (= its launch bound) per workgroup
 inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz) {
     const int nw = Nout / (16 * NB), wmax = NB == 3 ? 4 : 1024 / NB / 64;
-    const int wpb = nw < wmax ? nw : wmax;
+    int wpb = nw < wmax ? nw : wmax;
+    // prefer a multiple of 4 waves per workgroup that divides the wave count: every SIMD then holds the same
+    // number of waves (a SIMD with a single wave reaches only 3/4 of the MFMA issue rate)
+    for (int c = wpb - wpb % 4; c >= 4; c -= 4)
+        if (nw % c == 0) { wpb = c; break; }
     *block = dim3(wpb * 64);
     *gz = (unsigned)((nw + wpb - 1) / wpb);
 }
