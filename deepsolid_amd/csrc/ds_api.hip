@@ -74,6 +74,7 @@ struct ds_system {
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
     bool prof_on = false;
+    int prof_only = -1;               // >= 0: record events for this kernel kind only (keeps the timed region undisturbed)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[DS_PROF_KINDS];
     std::vector<hipEvent_t> prof_pool;
 };
@@ -88,7 +89,7 @@ struct ProfScope {
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
     ProfScope(ds_system* s_, int kind_, hipStream_t st_) : s(s_), kind(kind_), st(st_) {
-        if (s->prof_on) { e0 = get(s); e1 = get(s); (void)hipEventRecord(e0, st); }
+        if (s->prof_on && (s->prof_only < 0 || s->prof_only == kind)) { e0 = get(s); e1 = get(s); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
         if (e0) { (void)hipEventRecord(e1, st); s->prof_ev[kind].push_back({e0, e1}); }
@@ -916,6 +917,7 @@ int ds_profile_enable(ds_system* s, int on) {
         v.clear();
     }
     s->prof_on = on != 0;
+    s->prof_only = on >= 2 ? on - 2 : -1;      // on = 2 + kind: that kernel kind only
     return 0;
 }
 

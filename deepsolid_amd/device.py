@@ -349,9 +349,11 @@ class DeviceSystem:
         _lib.check(self.lib.ds_mh_accept(self.handle, _ptr(x1), _ptr(lp1), _ptr(x2), _ptr(lp2), _ptr(uniform),
                                          x1.shape[0], _ptr(n_accept), _stream()), 'ds_mh_accept')
 
-    def profile(self, on=True):
-        """Start (and reset) / stop per-kernel HIP-event timing inside the library."""
-        _lib.check(self.lib.ds_profile_enable(self.handle, int(bool(on))), 'ds_profile_enable')
+    def profile(self, on=True, only=None):
+        """Start (and reset) / stop per-kernel HIP-event timing inside the library; `only` = one
+        kernel kind of _lib.PROF_KINDS (events around that kernel only)."""
+        mode = 0 if not on else (1 if only is None else 2 + _lib.PROF_KINDS.index(only))
+        _lib.check(self.lib.ds_profile_enable(self.handle, mode), 'ds_profile_enable')
 
     def profile_read(self):
         """-> {kernel kind: (total ms, launches)} for the launches since profile(True)."""

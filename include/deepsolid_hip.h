@@ -168,7 +168,8 @@ int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_
                        void* ws, int64_t ws_bytes, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around every launch of the
- * local-energy chain (bench.py's roofline numbers).  ds_profile_enable(sys, 1) resets and starts,
+ * local-energy chain (bench.py's roofline numbers).  ds_profile_enable(sys, 1) resets and starts for every
+ * kernel, ds_profile_enable(sys, 2 + kind) for one kernel kind only (no events around the others), 0 stops;
  * ds_profile_read synchronises the recorded events and returns, per kernel kind, the summed
  * duration in ms and the number of launches (arrays of DS_PROF_KINDS entries). */
 #define DS_PROF_FEATURES 0
