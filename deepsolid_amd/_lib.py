@@ -46,6 +46,8 @@ SIGNATURES = {
     'ds_workspace_bytes': (C.c_int64, [_VP, C.c_int64]),
     'ds_logpsi': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, C.c_int64, _VP]),
     'ds_logpsi_grad': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
+    'ds_vjp_workspace_bytes': (C.c_int64, [_VP, C.c_int64]),
+    'ds_logpsi_vjp': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),
     'ds_orbitals': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, C.c_int64, _VP]),
     'ds_ewald': (C.c_int, [_VP, _VP, C.c_int64, _VP, _VP]),
     'ds_local_energy': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP]),

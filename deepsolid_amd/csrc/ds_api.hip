@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/deepsolid_hip.h"
-#include "ds_value.h"
+#include "ds_grad.h"
 
 namespace {
 
@@ -448,7 +448,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
         ProfScope ps(s, DS_PROF_DET_INVERSE, st);
         hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp,
-                           c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp], S.P, 16, 1);   // value = slot 0 of slot tile 0
+                           c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp], S.P, 16, 1, 1);   // value = slot 0 of slot tile 0
     }
     if (stop == STOP_MINV) return copy_out(dr, c.MINV, L.MINV * Bc, st);
     for (int sp = 0; sp < S.n_detch; ++sp) {
@@ -491,39 +491,70 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
 }
 
 // The value chain (log psi only) on `Bc` walkers = ceil(Bc / PV) groups; see ds_value.h.
+// Buffers of one value-chain pass over ng groups.  The plain pass ping-pongs two G / H2 buffers; the
+// gradient pass keeps every layer's activations (Gl[l] = input of layer l, Gl[n_layers] = orbital-head input).
+template <typename T> struct ValBufs {
+    T* Gl[DS_MAX_LAYERS + 1];
+    T* H2l[DS_MAX_LAYERS + 1];
+    T *MEAN0, *ZB, *Q, *MOUT, *DETS;
+    T* PHI[2];              // orbital GEMM output per spin channel (the plain pass reuses ZB for both)
+    T* SORB[2];             // use_last_layer: shared term of the orbital head
+    T* MINV;                // optional inverses, laid out like MOUT (walker-interleaved)
+};
+
 template <typename T>
-int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, hipStream_t st, T* out_logabs, T* out_phase,
-                    T** mout_ptr) {
+ValBufs<T> carve_value(ds_system* s, void* ws, int64_t ng) {
     const ds::SysDev<T>& S = dev<T>(s);
     const WsLayout& L = s->wsv;
-    const int PV = ds::PV;
-    const int64_t ng = (Bc + PV - 1) / PV;
+    ValBufs<T> b{};
     T* p = (T*)ws;
     T* G[2]; T* MEAN[2]; T* H2[2];
     G[0] = p; p += L.G * ng; G[1] = p; p += L.G * ng;
     MEAN[0] = p; p += L.MEAN * ng; MEAN[1] = p; p += L.MEAN * ng;
-    T* ZB = p; p += L.ZB * ng;
+    b.ZB = p; p += L.ZB * ng;
     H2[0] = p; p += L.H2 * ng; H2[1] = p; p += L.H2 * ng;
-    T* Q = p; p += L.Q * ng;
-    T* MOUT = p; p += L.MOUT * ng;
-    T* DETS = p; p += L.DETS * ng;
+    b.Q = p; p += L.Q * ng;
+    b.MOUT = p; p += L.MOUT * ng;
+    b.DETS = p; p += L.DETS * ng;
+    b.MEAN0 = MEAN[0];
+    for (int l = 0; l <= S.n_layers; ++l) { b.Gl[l] = G[l & 1]; b.H2l[l] = H2[l & 1]; }
+    for (int sp = 0; sp < 2; ++sp) {
+        const int ns = sp == 0 ? S.n_up : S.n_dn;
+        b.PHI[sp] = b.ZB;                                            // PHI first, S of the orbital head behind it
+        b.SORB[sp] = b.ZB + (size_t)ns * S.ocols[sp] * ds::PV * ng;
+    }
+    b.MINV = nullptr;
+    return b;
+}
+
+// The value chain (log psi / orbital matrices) on a chunk of Bc walkers.
+template <typename T>
+int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const ValBufs<T>& vb, hipStream_t st, T* out_logabs,
+                    T* out_phase) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const WsLayout& L = s->wsv;
+    const int PV = ds::PV;
+    const int64_t ng = (Bc + PV - 1) / PV;
+    T* ZB = vb.ZB; T* Q = vb.Q; T* MOUT = vb.MOUT; T* DETS = vb.DETS;
     auto blk = [&](int i) { return params + s->blocks[i].offset; };
     hipLaunchKernelGGL((ds::k_features_val<T, 0>), dim3((unsigned)ng, ds::FV_SPLIT), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
-                       blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), G[0], MEAN[0], H2[0], Q);
+                       blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), vb.Gl[0], vb.MEAN0, vb.H2l[0], Q);
     hipLaunchKernelGGL((ds::k_features_val<T, 1>), dim3((unsigned)ng, ds::FV_SPLIT), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
-                       blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), G[0], MEAN[0], H2[0], Q);
-    int gi = 0, hi = 0, mi = 0;
+                       blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), vb.Gl[0], vb.MEAN0, vb.H2l[0], Q);
     const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
-        hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, H2[hi], K2, G[gi], Kh);
+        T* Gin = vb.Gl[l]; T* Gout = vb.Gl[l + 1];
+        // the pair stream stops changing after the last two-electron layer
+        T* Hin = vb.H2l[l < S.n_double ? l : S.n_double];
+        hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, Hin, K2, Gin, Kh);
         if (l < S.n_double) {
             const int K2o = S.h2[l + 1];
             if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
             dim3 grid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
             const bool res = K2 == K2o;
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
-#define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, true>), grid, dim3(256), 0, st, S, H2[hi], K2, W2, b2, H2[hi ^ 1])
+#define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, true>), grid, dim3(256), 0, st, S, Hin, K2, W2, b2, vb.H2l[l + 1])
             if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
             else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
 #undef DS_TWO
@@ -534,50 +565,48 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void*
         gemm_geom(Nout, 4, &block, &gz);
         if (l == 0)
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
-                               (const T*)nullptr, 0, MEAN[0], (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
+                               (const T*)nullptr, 0, vb.MEAN0, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
                                (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
         else
-            hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, gz), block, 2 * 16 * PV * sizeof(T), st, S, G[gi],
+            hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, gz), block, 2 * 16 * PV * sizeof(T), st, S, Gin,
                                blk(s->i_wsh[l]), Kh, ZB, Nout, PV);
         if (Kh == Nout)
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, 0, st, G[gi], gws, gts, blk(s->i_wloc[l]), Kloc,
-                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, G[gi ^ 1], (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, 0, st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
         else
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 3>), dim3(S.N, (unsigned)ng, gz), block, 0, st, G[gi], gws, gts, blk(s->i_wloc[l]), Kloc,
-                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, G[gi ^ 1], (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
-        gi ^= 1;
-        if (l < S.n_double) hi ^= 1;
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 3>), dim3(S.N, (unsigned)ng, gz), block, 0, st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
     }
+    T* Gl = vb.Gl[S.n_layers];
     const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
-    if (s->use_last) hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, H2[hi], K2l, G[gi], Kl);
-    // PHI (GEMM output) and the orbital shared term both live in ZB: PHI first, S behind it
+    if (s->use_last) hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, vb.H2l[S.n_double], K2l, Gl, Kl);
     for (int sp = 0; sp < S.nch; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
         const int Korb = Kl + (s->use_last ? S.nch * K2l : 0);
         dim3 oblock; unsigned ogz;
         gemm_geom(OC, 4, &oblock, &ogz);
-        T* Sorb = ZB + (size_t)ns * OC * PV * ng;
+        T* PHI = vb.PHI[sp]; T* Sorb = vb.SORB[sp];
         if (s->use_last)
-            hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, ogz), oblock, 2 * 16 * PV * sizeof(T), st, S, G[gi],
+            hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, ogz), oblock, 2 * 16 * PV * sizeof(T), st, S, Gl,
                                blk(s->i_wsh_orb[sp]), Kl, Sorb, OC, PV);
-        hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, G[gi] + (size_t)i0 * S.ldk * PV,
-                           gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, ZB, (size_t)ns * OC * PV,
+        hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, Gl + (size_t)i0 * S.ldk * PV,
+                           gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, PHI, (size_t)ns * OC * PV,
                            OC, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
-        hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, ZB, (size_t)ns * OC * PV, Q, MOUT, sp,
+        hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, PHI, (size_t)ns * OC * PV, Q, MOUT, sp,
                            L.MOUT, L.mout_off[S.mat_ch[sp]], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr,
                            s->use_last ? (const T*)Sorb : (const T*)nullptr);
     }
-    if (mout_ptr) *mout_ptr = MOUT;
-    if (out_logabs || out_phase) {
+    if (out_logabs || out_phase || vb.MINV) {
         const size_t dstride = s->ws.DETS;
         for (int sp = 0; sp < S.n_detch; ++sp) {
             const int n = S.det_n[sp];
             size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
             hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, MOUT, L.MOUT, L.mout_off[sp], sp,
-                               (T*)nullptr, (size_t)0, (size_t)0, DETS, dstride, s->ws.dets_off[sp], PV, PV, PV);
+                               vb.MINV, L.MOUT, L.mout_off[sp], DETS, dstride, s->ws.dets_off[sp], PV, PV, PV, PV);
         }
-        hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, (const T*)nullptr, (size_t)0, (size_t)0, DETS, dstride,
-                           s->ws.dets_off[1], (T*)nullptr, out_logabs, out_phase, (T*)nullptr);
+        if (out_logabs || out_phase)
+            hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, (const T*)nullptr, (size_t)0, (size_t)0, DETS, dstride,
+                               s->ws.dets_off[1], (T*)nullptr, out_logabs, out_phase, (T*)nullptr);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -592,8 +621,9 @@ int logpsi_impl(ds_system* s, const void* params, const void* x, int64_t B, void
     const int64_t chunk = cg * ds::PV;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t Bc = std::min(chunk, B - b0);
-        int rc = run_value_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, ws, st, out_logabs ? (T*)out_logabs + b0 : nullptr,
-                                    out_phase ? (T*)out_phase + 2 * b0 : nullptr, nullptr);
+        const ValBufs<T> vb = carve_value<T>(s, ws, (Bc + ds::PV - 1) / ds::PV);
+        int rc = run_value_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, vb, st, out_logabs ? (T*)out_logabs + b0 : nullptr,
+                                    out_phase ? (T*)out_phase + 2 * b0 : nullptr);
         if (rc) return rc;
     }
     return 0;
@@ -608,8 +638,9 @@ int orbitals_impl(ds_system* s, const void* params, const void* x, int64_t B, vo
     const int64_t chunk = cg * ds::PV;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t Bc = std::min(chunk, B - b0);
-        T* mout = nullptr;
-        int rc = run_value_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, ws, st, nullptr, nullptr, &mout);
+        const ValBufs<T> vb = carve_value<T>(s, ws, (Bc + ds::PV - 1) / ds::PV);
+        T* mout = vb.MOUT;
+        int rc = run_value_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, vb, st, nullptr, nullptr);
         if (rc) return rc;
         for (int sp = 0; sp < S.n_detch; ++sp) {
             const int n = S.det_n[sp];
@@ -682,6 +713,212 @@ int logpsi_grad_impl(ds_system* s, const void* params, const void* x, int64_t B,
                               out_phase ? (T*)out_phase + 2 * b0 : nullptr, nullptr, (T*)out_grad + b0 * 3 * S.N * 2);
         if (rc) return rc;
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------ parameter gradient (reverse sweep, ds_grad.h)
+struct GradPlan {
+    size_t wt_total;                 // transposed weights, shared by all groups (elements)
+    size_t wlocT[DS_MAX_LAYERS], wshT[DS_MAX_LAYERS], worbT[2];
+    int kpad[DS_MAX_LAYERS];         // rows of W * ZBAR per layer (Kloc rounded up to the GEMM's 64-feature blocks)
+    size_t per_group;                // elements per group of PV walkers
+    size_t phi_off[2], phi_total, gbar, hb, h2;
+};
+
+int grad_plan(const ds_system* s, GradPlan* gp) {
+    const ds::SysDev<double>& S = s->sd;
+    const size_t PV = ds::PV;
+    if (s->use_last) return fail("parameter gradient: use_last_layer is not supported");
+    if (S.env_type != 0) return fail("parameter gradient: only the isotropic envelope is supported");
+    if (S.bias_orb) return fail("parameter gradient: bias_orbitals is not supported");
+    if (S.n_double != S.n_layers - 1) return fail("parameter gradient: unexpected layer counts");
+    size_t off = 0;
+    int h1max = 0, h2max = 0, kpmax = S.h1[S.n_layers];
+    for (int l = 0; l <= S.n_layers; ++l) { h1max = std::max(h1max, S.h1[l]); h2max = std::max(h2max, S.h2[l]); }
+    for (int l = 0; l < S.n_layers; ++l) {
+        const int Kh = S.h1[l], Nout = S.h1[l + 1], Kloc = Kh + S.nch * S.h2[l];
+        gp->kpad[l] = rup(Kloc, 64);
+        gp->wlocT[l] = off; if (l > 0) off += (size_t)Nout * gp->kpad[l];
+        gp->wshT[l] = off; if (l > 0) off += (size_t)Nout * S.nch * Kh;
+        if (l > 0) kpmax = std::max(kpmax, gp->kpad[l]);
+    }
+    for (int c = 0; c < S.nch; ++c) { gp->worbT[c] = off; off += (size_t)S.ocols[c] * S.h1[S.n_layers]; }
+    gp->wt_total = rup((int)off, 16);
+    size_t phi = 0;
+    for (int c = 0; c < S.nch; ++c) { gp->phi_off[c] = phi; phi += (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * PV; }
+    gp->phi_total = phi;
+    gp->gbar = (size_t)S.N * kpmax * PV;
+    gp->hb = (size_t)S.N * h1max * PV;
+    gp->h2 = (size_t)(PV / 5) * h2max * 5 * S.NP;
+    const WsLayout& v = s->wsv;
+    gp->per_group = (size_t)(S.n_layers + 1) * v.G + (size_t)(S.n_double + 1) * gp->h2 + 3 * v.MEAN + v.ZB + 2 * v.Q + 2 * v.MOUT + v.DETS +
+                    2 * phi + (size_t)S.K * 2 * PV + gp->gbar + 3 * gp->hb + (size_t)h1max * PV + 3 * gp->h2 + (size_t)s->nparams;
+    return 0;
+}
+
+template <typename T>
+int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B, const void* cot_, void* grad_, void* out_logabs,
+                    void* out_phase, void* ws, int64_t ws_bytes, hipStream_t st) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const int PV = ds::PV;
+    GradPlan gp;
+    if (int rc = grad_plan(s, &gp)) return rc;
+    const T* params = (const T*)params_;
+    const T* cot = (const T*)cot_;
+    T* grad = (T*)grad_;
+    const int64_t avail = ws_bytes / (int64_t)sizeof(T) - (int64_t)gp.wt_total;
+    const int64_t cg = avail / (int64_t)gp.per_group;
+    if (cg < 1) return fail("workspace too small for the parameter gradient: %lld bytes", (long long)ws_bytes);
+    auto blk = [&](int i) { return params + s->blocks[i].offset; };
+    auto boff = [&](int i) { return (size_t)s->blocks[i].offset; };
+    T* WT = (T*)ws;
+    const int L = S.n_layers, Kl = S.h1[L];
+    auto transpose = [&](const T* W, int rows, int cols, T* out, int ldt) {
+        const size_t n = (size_t)cols * ldt;
+        hipLaunchKernelGGL((ds::k_transpose_pad<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, rows, cols, out, ldt);
+    };
+    for (int l = 1; l < L; ++l) {
+        const int Kh = S.h1[l], Nout = S.h1[l + 1], Kloc = Kh + S.nch * S.h2[l];
+        transpose(blk(s->i_wloc[l]), Kloc, Nout, WT + gp.wlocT[l], gp.kpad[l]);
+        transpose(blk(s->i_wsh[l]), S.nch * Kh, Nout, WT + gp.wshT[l], S.nch * Kh);
+    }
+    for (int c = 0; c < S.nch; ++c) transpose(blk(s->i_worb[c]), Kl, S.ocols[c], WT + gp.worbT[c], Kl);
+    const size_t np = (size_t)s->nparams;
+    const WsLayout& V = s->wsv;
+    int h1max = 0;
+    for (int l = 0; l <= L; ++l) h1max = std::max(h1max, S.h1[l]);
+    bool first = true;
+    for (int64_t b0 = 0; b0 < B; b0 += cg * PV) {
+        const int64_t Bc = std::min<int64_t>(cg * PV, B - b0), ng = (Bc + PV - 1) / PV;
+        const T* x = (const T*)x_ + b0 * 3 * S.N;
+        // ---- carve
+        T* p = WT + gp.wt_total;
+        ValBufs<T> vb{};
+        for (int l = 0; l <= L; ++l) { vb.Gl[l] = p; p += V.G * ng; }
+        for (int l = 0; l <= S.n_double; ++l) { vb.H2l[l] = p; p += gp.h2 * ng; }
+        for (int l = S.n_double + 1; l <= L; ++l) vb.H2l[l] = vb.H2l[S.n_double];
+        vb.MEAN0 = p; p += V.MEAN * ng;
+        T* MEANL = p; p += V.MEAN * ng;
+        T* MEANBAR = p; p += V.MEAN * ng;
+        vb.ZB = p; p += V.ZB * ng;
+        vb.Q = p; p += V.Q * ng;
+        T* QBAR = p; p += V.Q * ng;
+        vb.MOUT = p; p += V.MOUT * ng;
+        vb.MINV = p; p += V.MOUT * ng;
+        vb.DETS = p; p += V.DETS * ng;
+        T* PB[2] = {nullptr, nullptr};
+        for (int c = 0; c < S.nch; ++c) { vb.PHI[c] = p + gp.phi_off[c] * ng; vb.SORB[c] = nullptr; }
+        p += gp.phi_total * ng;
+        for (int c = 0; c < S.nch; ++c) PB[c] = p + gp.phi_off[c] * ng;
+        p += gp.phi_total * ng;
+        T* CW = p; p += (size_t)S.K * 2 * PV * ng;
+        T* GBAR = p; p += gp.gbar * ng;
+        T* HB[2]; HB[0] = p; p += gp.hb * ng; HB[1] = p; p += gp.hb * ng;
+        T* ZBAR = p; p += gp.hb * ng;
+        T* SBAR = p; p += (size_t)h1max * PV * ng;
+        T* H2BAR[2]; H2BAR[0] = p; p += gp.h2 * ng; H2BAR[1] = p; p += gp.h2 * ng;
+        T* Z2BAR = p; p += gp.h2 * ng;
+        T* PART = p; p += np * ng;
+        // ---- forward with every activation kept
+        int rc = run_value_chain<T>(s, params, x, Bc, vb, st, out_logabs ? (T*)out_logabs + b0 : nullptr,
+                                    out_phase ? (T*)out_phase + 2 * b0 : nullptr);
+        if (rc) return rc;
+        HIP_OK(hipMemsetAsync(PART, 0, np * ng * sizeof(T), st));
+        // ---- determinants -> orbital head
+        hipLaunchKernelGGL((ds::k_det_weights<T>), dim3((unsigned)((ng * PV + 63) / 64)), dim3(64), 0, st, S, vb.DETS, s->ws.DETS,
+                           s->ws.dets_off[1], cot + 2 * b0, (long)Bc, CW);
+        const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
+        auto outer = [&](const T* X, size_t xg, size_t xt, int ldx, const T* Z, size_t zg, size_t zt, int ldz, int nt, int J, int K,
+                         int Nc, size_t off) {
+            const int nwt = ((K + 31) / 32) * ((Nc + 31) / 32);
+            hipLaunchKernelGGL((ds::k_outer_gemm<T>), dim3((unsigned)((nwt + 3) / 4), (unsigned)ng), dim3(256), 0, st, X, xg, xt, ldx, Z, zg,
+                               zt, ldz, nt, J, K, Nc, PART + off, np);
+        };
+        for (int sp = 0; sp < S.nch; ++sp) {
+            const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
+            const size_t pgs = (size_t)ns * OC * PV;
+            HIP_OK(hipMemsetAsync(PB[sp], 0, pgs * ng * sizeof(T), st));
+            hipLaunchKernelGGL((ds::k_orbital_bwd<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, vb.PHI[sp], pgs, vb.Q, vb.MINV, V.MOUT,
+                               V.mout_off[S.mat_ch[sp]], CW, sp, (long)Bc, S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, PB[sp], QBAR);
+            outer(vb.Gl[L] + (size_t)i0 * S.ldk * PV, gws, gts, PV, PB[sp], pgs, (size_t)OC * PV, PV, ns, PV, Kl, OC, boff(s->i_worb[sp]));
+            dim3 block; unsigned gz;
+            gemm_geom(Kl, 4, &block, &gz);
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, gz), block, 0, st, PB[sp], pgs, (size_t)OC * PV,
+                               WT + gp.worbT[sp], OC, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, GBAR + (size_t)i0 * Kl * PV,
+                               (size_t)S.N * Kl * PV, Kl, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+        }
+        hipLaunchKernelGGL((ds::k_env_grad<T>), dim3((unsigned)ng, S.nch), dim3(256), 0, st, S, x, (long)b0, (long)Bc, vb.Gl[0], QBAR,
+                           blk(s->i_pi[0]), blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), PART, np,
+                           (long)boff(s->i_pi[0]), (long)boff(s->i_sg[0]), (long)boff(s->i_pi[S.nch - 1]), (long)boff(s->i_sg[S.nch - 1]));
+        // ---- layers, last to first
+        const T* D1 = GBAR; int ld1 = Kl; const T* MB = nullptr; const T* CARRY = nullptr;
+        int hbi = 0, h2i = 0;
+        for (int l = L - 1; l >= 0; --l) {
+            const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1], Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
+            const bool res = Kh == Nout;
+            T* HBc = HB[hbi];
+            if (res)
+                hipLaunchKernelGGL((ds::k_layer_bwd_prep<T, true>), dim3(Nout / 4, (unsigned)ng), dim3(4 * PV), 0, st, S, D1, ld1, MB, CARRY,
+                                   vb.Gl[l + 1], vb.Gl[l], Nout, HBc, ZBAR, SBAR, PART + boff(s->i_b[l]), np);
+            else
+                hipLaunchKernelGGL((ds::k_layer_bwd_prep<T, false>), dim3(Nout / 4, (unsigned)ng), dim3(4 * PV), 0, st, S, D1, ld1, MB, CARRY,
+                                   vb.Gl[l + 1], vb.Gl[l], Nout, HBc, ZBAR, SBAR, PART + boff(s->i_b[l]), np);
+            outer(vb.Gl[l], gws, gts, PV, ZBAR, (size_t)S.N * Nout * PV, (size_t)Nout * PV, PV, S.N, PV, Kloc, Nout, boff(s->i_wloc[l]));
+            const T* MEANl = vb.MEAN0;
+            if (l > 0) {
+                hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)((S.nch * Kh * PV + 255) / 256), (unsigned)ng), dim3(256), 0, st, S,
+                                   vb.Gl[l], Kh, MEANL);
+                MEANl = MEANL;
+            }
+            outer(MEANl, (size_t)Ksh * PV, 0, PV, SBAR, (size_t)Nout * PV, 0, PV, 1, PV, Ksh, Nout, boff(s->i_wsh[l]));
+            const int Kpad = gp.kpad[l];
+            if (l > 0) {
+                dim3 block; unsigned gz;
+                gemm_geom(Kpad, 4, &block, &gz);
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(S.N, (unsigned)ng, gz), block, 0, st, ZBAR, (size_t)S.N * Nout * PV,
+                                   (size_t)Nout * PV, WT + gp.wlocT[l], Nout, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, GBAR,
+                                   (size_t)S.N * Kpad * PV, Kpad, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                gemm_geom(Ksh, 4, &block, &gz);
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0,
+                                   (size_t)0, (const T*)nullptr, 0, SBAR, (size_t)Nout * PV, WT + gp.wshT[l], Nout, 0, MEANBAR,
+                                   (size_t)Ksh * PV, Ksh, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+            }
+            // pair stream
+            const dim3 pgrid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
+            if (l == S.n_double) {
+                if (l > 0)
+                    hipLaunchKernelGGL((ds::k_pair_scatter<T>), dim3((S.NP + 255) / 256, K2 * 5, (unsigned)(ng * (PV / 5))), dim3(256), 0, st, S,
+                                       GBAR, Kpad, Kh, K2, H2BAR[h2i]);
+            } else {
+                const int K2o = S.h2[l + 1];
+                const bool res2 = K2 == K2o, dx = l > 0;
+                const T* W2 = blk(s->i_w2[l]);
+                T* HBn = H2BAR[h2i]; T* HBi = H2BAR[h2i ^ 1];
+#define DS_TWOB(NTI, NTO, RES, DX) hipLaunchKernelGGL((ds::k_two_bwd<T, NTI, NTO, RES, DX>), pgrid, dim3(256), 0, st, S, HBn, vb.H2l[l + 1], \
+                                                      vb.H2l[l], W2, GBAR, Kpad, Kh, Z2BAR, HBi)
+                if (!dx) { if (K2o == 32) DS_TWOB(1, 2, false, false); else DS_TWOB(1, 1, false, false); }
+                else if (K2 == 32 && K2o == 32) DS_TWOB(2, 2, true, true);
+                else if (K2 == 16 && K2o == 16) DS_TWOB(1, 1, true, true);
+                else if (K2 == 32 && K2o == 16) DS_TWOB(2, 1, false, true);
+                else if (K2 == 16 && K2o == 32) DS_TWOB(1, 2, false, true);
+                else return fail("parameter gradient: unsupported pair-stream widths %d -> %d", K2, K2o);
+#undef DS_TWOB
+                (void)res2;
+                const int J = 5 * S.NP;
+                outer(vb.H2l[l], (size_t)(PV / 5) * K2 * J, (size_t)K2 * J, J, Z2BAR, (size_t)(PV / 5) * K2o * J, (size_t)K2o * J, J, PV / 5,
+                      J, K2, K2o, boff(s->i_w2[l]));
+                hipLaunchKernelGGL((ds::k_row_sums<T>), dim3(K2o, (unsigned)ng), dim3(256), 0, st, Z2BAR, (size_t)(PV / 5) * K2o * J,
+                                   (size_t)K2o * J, J, PV / 5, J, PART + boff(s->i_b2[l]), np);
+                h2i ^= 1;
+            }
+            D1 = GBAR; ld1 = Kpad; MB = MEANBAR; CARRY = res ? HBc : nullptr;
+            hbi ^= 1;
+        }
+        hipLaunchKernelGGL((ds::k_reduce_partials<T>), dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, PART, np, (long)ng, (long)np,
+                           first ? 0 : 1, grad);
+        first = false;
+    }
+    HIP_OK(hipGetLastError());
     return 0;
 }
 
@@ -800,6 +1037,29 @@ int ds_logpsi_grad(ds_system* s, const void* params, const void* x, int64_t B, v
     hipStream_t st = (hipStream_t)stream;
     return s->dtype == 0 ? logpsi_grad_impl<double>(s, params, x, B, out_logabs, out_phase, out_grad, ws, ws_bytes, st)
                          : logpsi_grad_impl<float>(s, params, x, B, out_logabs, out_phase, out_grad, ws, ws_bytes, st);
+}
+
+int64_t ds_vjp_workspace_bytes(const ds_system* s, int64_t B) {
+    if (!s) return -1;
+    GradPlan gp;
+    if (grad_plan(s, &gp)) return -1;
+    const int64_t esz = s->dtype == 0 ? 8 : 4;
+    const int64_t budget = (int64_t)32 << 30;
+    int64_t groups = std::min<int64_t>((std::max<int64_t>(B, 1) + ds::PV - 1) / ds::PV, 64);
+    groups = std::max<int64_t>(1, std::min<int64_t>(groups, budget / ((int64_t)gp.per_group * esz)));
+    return ((int64_t)gp.wt_total + (int64_t)gp.per_group * groups) * esz + 256;
+}
+
+int ds_logpsi_vjp(ds_system* s, const void* params, const void* x, int64_t B, const void* cot, void* grad, void* out_logabs,
+                  void* out_phase, void* ws, int64_t ws_bytes, void* stream) {
+    if (!s || !params || !x || !cot || !grad || !ws) return fail("null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (B <= 0) {
+        if (hipMemsetAsync(grad, 0, (size_t)s->nparams * (s->dtype == 0 ? 8 : 4), st) != hipSuccess) return fail("hipMemsetAsync failed");
+        return 0;
+    }
+    return s->dtype == 0 ? logpsi_vjp_impl<double>(s, params, x, B, cot, grad, out_logabs, out_phase, ws, ws_bytes, st)
+                         : logpsi_vjp_impl<float>(s, params, x, B, cot, grad, out_logabs, out_phase, ws, ws_bytes, st);
 }
 
 int ds_ewald(ds_system* s, const void* x, int64_t B, void* out, void* stream) {

@@ -284,11 +284,12 @@ template <typename T>
 __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                     int sp, T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                     T* __restrict__ DETS, size_t dets_stride, size_t dets_off, int P,
-                                                    int es, int cols_per_group) {
+                                                    int es, int cols_per_group, int ms) {
     // P = slots per matrix element (sets the per-determinant block size), es = stride between consecutive
     // (elec, orb, re/im) entries of the value:
     //   forward-Laplacian chain: P = S.P, es = 16 (slot 0 of slot tile 0), cols_per_group = 1;
     //   value chain: P = es = PV, cols_per_group = PV (walker w = column w % PV of group w / PV)
+    // ms = element stride of the inverse: 1 (per-walker blocks, minv_stride apart) or PV (interleaved like MOUT)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Cx<T>* aug = reinterpret_cast<Cx<T>*>(smem_raw);   // [n][2n]
     const int kdet = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
@@ -344,11 +345,11 @@ __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __rest
         __syncthreads();
     }
     if (MINV) {
-        T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
+        T* Iw = MINV + (size_t)(w / cols_per_group) * minv_stride + minv_off + (size_t)kdet * n * n * 2 * ms + w % cols_per_group;
         for (int idx = lane; idx < n * n; idx += 64) {
             const int r = idx / n, c = idx % n;
-            Iw[2 * idx] = aug[r * n2 + n + c].re;
-            Iw[2 * idx + 1] = aug[r * n2 + n + c].im;
+            Iw[(size_t)(2 * idx) * ms] = aug[r * n2 + n + c].re;
+            Iw[(size_t)(2 * idx + 1) * ms] = aug[r * n2 + n + c].im;
         }
     }
     if (lane == 0) {

@@ -186,8 +186,9 @@ class DeviceSystem:
         def dev(a):
             if not isinstance(a, torch.Tensor):
                 a = torch.as_tensor(np.asarray(a))
-            return a.to(device=self.device, dtype=self.dtype)
-        flat = torch.zeros(self.param_count, dtype=self.dtype, device=self.device)
+            return a.to(device=self.device, dtype=pdt)
+        pdt = getattr(self, '_pack_dtype', None) or self.dtype     # _grad_index packs entry numbers in float64
+        flat = torch.zeros(self.param_count, dtype=pdt, device=self.device)
         nch = 2 if self.nelec[1] > 0 else 1
         bi = iter(self.blocks)
 
@@ -235,7 +236,7 @@ class DeviceSystem:
                 src = self._orbital_column_map(nparam, cols)
                 if mat.shape[0] != rows:
                     raise ValueError(f"orbital[{c}]['w'] block has {mat.shape[0]} rows, expected {rows}")
-                packed = torch.zeros(rows, cols, dtype=self.dtype, device=self.device)
+                packed = torch.zeros(rows, cols, dtype=pdt, device=self.device)
                 valid = src >= 0
                 packed[:, torch.as_tensor(np.nonzero(valid)[0], device=self.device)] = \
                     mat[:, torch.as_tensor(src[valid], device=self.device)]
@@ -319,6 +320,98 @@ class DeviceSystem:
             _lib.check(self.lib.ds_logpsi_grad(self.handle, _ptr(p), _ptr(x), B, _ptr(la), _ptr(None), _ptr(gr), _ptr(ws),
                                                ws.numel(), _stream()), 'ds_logpsi_grad')
         return la, torch.view_as_complex(gr)
+
+    def logpsi_vjp(self, params, x, cot):
+        """Packed parameter gradient of sum_b Re(conj(cot_b) * log psi_b), log psi = log|psi| + i arg psi
+        (`ds_logpsi_vjp`): cot (B,) complex or (B, 2) real.  -> (flat grad (param_count,), log|psi| (B,),
+        phase (B,) complex).  `unpack_grad` turns the flat vector into the reference's parameter tree."""
+        x = self._check_x(x)
+        B = x.shape[0]
+        if cot.is_complex():
+            cot = torch.view_as_real(cot)
+        cot = cot.to(device=self.device, dtype=self.dtype).contiguous()
+        if tuple(cot.shape) != (B, 2):
+            raise ValueError(f'cot must be ({B},) complex or ({B}, 2), got {tuple(cot.shape)}')
+        p = self.pack_params(params)
+        need = int(self.lib.ds_vjp_workspace_bytes(self.handle, int(B)))
+        if need < 0:
+            _lib.check(1, 'ds_vjp_workspace_bytes')
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws
+        grad = torch.empty(self.param_count, dtype=self.dtype, device=self.device)
+        la = torch.empty(B, dtype=self.dtype, device=self.device)
+        ph = torch.empty(B, 2, dtype=self.dtype, device=self.device)
+        _lib.check(self.lib.ds_logpsi_vjp(self.handle, _ptr(p), _ptr(x), B, _ptr(cot), _ptr(grad), _ptr(la), _ptr(ph), _ptr(ws),
+                                          ws.numel(), _stream()), 'ds_logpsi_vjp')
+        return grad, la, torch.view_as_complex(ph)
+
+    def _grad_index(self, params):
+        """For every leaf of the parameter tree: positions of its entries in the packed buffer (the packing
+        is a gather with zero padding, so its transpose is one index_select per leaf).  Found by packing a
+        tree whose leaves hold their own running entry number."""
+        shapes = []
+
+        def walk(o):
+            if isinstance(o, dict):
+                return {k: walk(o[k]) for k in sorted(o)}
+            if isinstance(o, (list, tuple)):
+                return [walk(v) for v in o]
+            t = torch.as_tensor(np.asarray(o)) if not isinstance(o, torch.Tensor) else o
+            shapes.append(tuple(t.shape))
+            return None
+        walk(params)
+        key = tuple(shapes)
+        if getattr(self, '_gidx_key', None) == key:
+            return self._gidx
+        counter = [1]
+
+        def number(o):
+            if isinstance(o, dict):
+                return {k: number(o[k]) for k in sorted(o)}
+            if isinstance(o, (list, tuple)):
+                return [number(v) for v in o]
+            t = torch.as_tensor(np.asarray(o)) if not isinstance(o, torch.Tensor) else o
+            n = t.numel()
+            out = torch.arange(counter[0], counter[0] + n, dtype=torch.float64).reshape(t.shape)
+            counter[0] += n
+            return out
+        numbered = number(params)
+        saved = (self._packed, self._packed_key)
+        try:
+            self._pack_dtype = torch.float64    # entry numbers must survive the packing exactly
+            self._packed = None
+            flat = self.pack_params(numbered).round().to(torch.int64)
+        finally:
+            self._pack_dtype = None
+            self._packed, self._packed_key = saved
+        total = counter[0] - 1
+        pos = torch.full((total + 1,), -1, dtype=torch.int64, device=self.device)
+        nz = torch.nonzero(flat > 0).reshape(-1)
+        pos[flat[nz]] = nz
+        self._gidx, self._gidx_key = pos[1:], key
+        return self._gidx
+
+    def unpack_grad(self, flat, params):
+        """Packed gradient -> a tree shaped like `params` (reference layout, network.py:135-186)."""
+        pos = self._grad_index(params)
+        if bool((pos < 0).any()):
+            raise RuntimeError('parameter entries without a place in the packed buffer')
+        vals = flat[pos]
+        off = [0]
+
+        def build(o):
+            if isinstance(o, dict):
+                return {k: build(o[k]) for k in sorted(o)}
+            if isinstance(o, (list, tuple)):
+                return [build(v) for v in o]
+            t = torch.as_tensor(np.asarray(o)) if not isinstance(o, torch.Tensor) else o
+            n = t.numel()
+            out = vals[off[0]:off[0] + n].reshape(t.shape)
+            off[0] += n
+            return out
+        return build(params)
 
     def orbitals(self, params, x):
         x = self._check_x(x)

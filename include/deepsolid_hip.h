@@ -129,6 +129,19 @@ int ds_logpsi(ds_system* sys, const void* params, const void* x, int64_t B,
 int ds_logpsi_grad(ds_system* sys, const void* params, const void* x, int64_t B,
                    void* out_logabs, void* out_phase, void* out_grad, void* ws, int64_t ws_bytes, void* stream);
 
+/* Parameter gradient of  L = sum_b [ cot[b][0] * log|psi_b| + cot[b][1] * arg psi_b ]  (reverse sweep over
+ * the value chain).  This is the vector-Jacobian product the reference obtains from jax.jvp / jax.grad of
+ * batch_network inside the custom JVP of total_energy (train.py:91-142): with cot = clip_diff / B (Re, Im)
+ * the result is  tangents_dot = mean(Re(clip_diff * conj(d log psi)))  for every parameter direction, i.e.
+ * the energy gradient jax.value_and_grad(total_energy) returns (train.py:147-176, process.py:226-228).
+ * cot (B, 2); grad (ds_param_count(),) in the packed layout of ds_param_layout, overwritten (padding entries
+ * are zero); out_logabs / out_phase optional.  Supported network options: isotropic envelope,
+ * use_last_layer = 0, bias_orbitals = 0 (others return an error).  Weight gradients are reduced over
+ * walkers in a fixed order (no atomics): the result is bit-reproducible run to run. */
+int64_t ds_vjp_workspace_bytes(const ds_system* sys, int64_t B);
+int ds_logpsi_vjp(ds_system* sys, const void* params, const void* x, int64_t B, const void* cot, void* grad,
+                  void* out_logabs, void* out_phase, void* ws, int64_t ws_bytes, void* stream);
+
 /* network.eval_func method 'eval_mats' (network.py:601): out_up (B, n_det, n_up, n_up, 2),
  * out_dn (B, n_det, n_dn, n_dn, 2), complex as (Re, Im) pairs. */
 int ds_orbitals(ds_system* sys, const void* params, const void* x, int64_t B,
