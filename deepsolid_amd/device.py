@@ -321,7 +321,7 @@ class DeviceSystem:
                                                ws.numel(), _stream()), 'ds_logpsi_grad')
         return la, torch.view_as_complex(gr)
 
-    def logpsi_vjp(self, params, x, cot):
+    def logpsi_vjp(self, params, x, cot, max_bytes=None):
         """Packed parameter gradient of sum_b Re(conj(cot_b) * log psi_b), log psi = log|psi| + i arg psi
         (`ds_logpsi_vjp`): cot (B,) complex or (B, 2) real.  -> (flat grad (param_count,), log|psi| (B,),
         phase (B,) complex).  `unpack_grad` turns the flat vector into the reference's parameter tree."""
@@ -333,13 +333,19 @@ class DeviceSystem:
         if tuple(cot.shape) != (B, 2):
             raise ValueError(f'cot must be ({B},) complex or ({B}, 2), got {tuple(cot.shape)}')
         p = self.pack_params(params)
+        if B == 0:
+            return (torch.zeros(self.param_count, dtype=self.dtype, device=self.device),
+                    torch.empty(0, dtype=self.dtype, device=self.device),
+                    torch.empty(0, dtype=torch.complex128 if self.dtype == torch.float64 else torch.complex64, device=self.device))
         need = int(self.lib.ds_vjp_workspace_bytes(self.handle, int(B)))
         if need < 0:
             _lib.check(1, 'ds_vjp_workspace_bytes')
+        if max_bytes is not None:
+            need = min(need, int(max_bytes))      # fewer walker groups per pass (the library chunks the batch)
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        ws = self._ws
+        ws = self._ws[:need]
         grad = torch.empty(self.param_count, dtype=self.dtype, device=self.device)
         la = torch.empty(B, dtype=self.dtype, device=self.device)
         ph = torch.empty(B, 2, dtype=self.dtype, device=self.device)

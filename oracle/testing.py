@@ -25,6 +25,32 @@ def make_test_params(seed, prim_atoms, nelec, net_kw, env_jitter=0.2):
     return params
 
 
+def make_test_direction(seed, params):
+    """A parameter-space direction shaped like `params` (numpy default_rng(seed), leaves visited in
+    sorted-key order, each scaled by the leaf's rms): the finite-difference fixtures of the parameter
+    gradient (tools/make_golden.py 'gradfd_*') are directional derivatives along it."""
+    rng = np.random.default_rng(seed)
+
+    def walk(o):
+        if isinstance(o, dict):
+            return {k: walk(o[k]) for k in sorted(o)}
+        if isinstance(o, (list, tuple)):
+            return [walk(v) for v in o]
+        a = np.asarray(o, dtype=np.float64)
+        rms = float(np.sqrt(np.mean(a * a))) if a.size else 1.0
+        return rng.normal(size=a.shape) * (rms if rms > 0 else 1.0)
+    return walk(params)
+
+
+def tree_axpy(params, h, direction):
+    """params + h * direction, leaf by leaf (numpy)."""
+    if isinstance(params, dict):
+        return {k: tree_axpy(params[k], h, direction[k]) for k in params}
+    if isinstance(params, (list, tuple)):
+        return [tree_axpy(p, h, d) for p, d in zip(params, direction)]
+    return np.asarray(params, dtype=np.float64) + h * np.asarray(direction)
+
+
 def params_checksum(params):
     tot, tot2 = 0.0, 0.0
 
@@ -59,15 +85,15 @@ def klist_from_kpts(kpts, nelec):
 # name -> recipe.  `system` keys deepsolid_amd.systems.SYSTEMS.
 CASES = {
     'h2':            dict(system='h2', seed=11, batch=4, fd_walkers=2),
-    'lih':           dict(system='lih', seed=12, batch=6, fd_walkers=3),
-    'lih_twist':     dict(system='lih', seed=13, batch=4, twist=(0.25, 0.1, 0.4), fd_walkers=2),
+    'lih':           dict(system='lih', seed=12, batch=6, fd_walkers=3, gradfd_walkers=3),
+    'lih_twist':     dict(system='lih', seed=13, batch=4, twist=(0.25, 0.1, 0.4), fd_walkers=2, gradfd_walkers=2),
     'lih_2x1x1':     dict(system='lih', seed=14, batch=3, system_kw=dict(S=np.diag([2, 1, 1])), mcmc=False),
-    'bcc_li':        dict(system='bcc_li', seed=15, batch=4, fd_walkers=1, fd_h=5e-4, fd_tol=1e-5),
+    'bcc_li':        dict(system='bcc_li', seed=15, batch=4, fd_walkers=1, fd_h=5e-4, fd_tol=1e-5, gradfd_walkers=2),
     'bcc_li_twist':  dict(system='bcc_li', seed=16, batch=2, twist=(0.3, 0.0, 0.15), mcmc=False),
     'graphene':      dict(system='graphene', seed=17, batch=2, mcmc=False),
     'diamond':       dict(system='diamond', seed=18, batch=2, mcmc=False),
-    'lih_fulldet':   dict(system='lih', seed=19, batch=3, net_kw=dict(full_det=True), mcmc=False),
-    'lih_tri':       dict(system='lih', seed=20, batch=3, net_kw=dict(distance_type='tri'), mcmc=False),
+    'lih_fulldet':   dict(system='lih', seed=19, batch=3, net_kw=dict(full_det=True), mcmc=False, gradfd_walkers=2),
+    'lih_tri':       dict(system='lih', seed=20, batch=3, net_kw=dict(distance_type='tri'), mcmc=False, gradfd_walkers=2),
     'lih_diagenv':   dict(system='lih', seed=21, batch=3, net_kw=dict(envelope_type='diagonal'), mcmc=False),
     'lih_fullenv':   dict(system='lih', seed=22, batch=3, net_kw=dict(envelope_type='full'), mcmc=False),
     'lih_lastlayer': dict(system='lih', seed=26, batch=3, net_kw=dict(use_last_layer=True), mcmc=False),

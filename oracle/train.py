@@ -71,6 +71,7 @@ def make_loss(network, simulation_cell, mode='for', partition_number=3, clip_loc
                                                partition_number=partition_number)
 
     def total_energy(params, data):
+        params = params_to_torch(params)
         kes, ews = zip(*[el_fun(params, x) for x in data])        # vmap(el_fun, (None, 0)) :64
         ke = torch.stack([k.to(torch.complex128) for k in kes])
         ew = torch.stack(list(ews))

@@ -1,0 +1,198 @@
+"""GPU parity of the parameter gradient (reference train.py:91-142):
+`ds_logpsi_vjp` through the C ABI against (1) torch autograd over the CPU oracle and (2) finite
+differences of the REFERENCE-executed forward stored in tests/golden (gradfd_*).
+
+Tolerances (float64): 1e-9 relative to the largest entry of each parameter leaf against the oracle;
+against the reference finite differences the fixtures' own truncation error (2e-7 absolute)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import train as otrain
+from oracle.testing import make_test_direction
+
+from common import load_case, oracle_net
+from deepsolid_amd import systems
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_params(params, dtype=torch.float64):
+    return {k: [{kk: torch.as_tensor(np.asarray(vv), dtype=dtype, device='cuda') for kk, vv in d.items()} for d in v]
+            for k, v in params.items()}
+
+
+def system_for(cell, klist, net_kw, dtype=torch.float64):
+    from deepsolid_amd.device import DeviceSystem
+    return DeviceSystem.for_network(cell, klist, net_kw, dtype)
+
+
+def leaves(tree):
+    if isinstance(tree, dict):
+        for k in sorted(tree):
+            yield from leaves(tree[k])
+    elif isinstance(tree, (list, tuple)):
+        for v in tree:
+            yield from leaves(v)
+    else:
+        yield tree
+
+
+def tree_dot(tree, direction):
+    return sum(float((a.double().cpu() * torch.as_tensor(np.asarray(d))).sum()) for a, d in zip(leaves(tree), leaves(direction)))
+
+
+def assert_tree_close(got, ref, rtol):
+    for g, r in zip(leaves(got), leaves(ref)):
+        g = g.double().cpu().numpy()
+        r = r.detach().numpy() if isinstance(r, torch.Tensor) else np.asarray(r)
+        assert g.shape == r.shape
+        scale = max(np.abs(r).max(), 1e-12)
+        assert np.abs(g - r).max() <= rtol * scale, (g.shape, np.abs(g - r).max(), scale)
+
+
+@pytest.mark.parametrize('name,batch', [('h2', 5), ('lih', 7), ('lih_twist', 4), ('lih_2x1x1', 3), ('bcc_li', 5),
+                                        ('lih_fulldet', 4), ('lih_tri', 4), ('bcc_li_fulldet', 2), ('graphene', 2)])
+def test_vjp_vs_oracle_autograd(name, batch):
+    fx, cell, klist, net_kw, params = load_case(name)
+    sysd = system_for(cell, klist, net_kw)
+    x = systems.synthetic_walkers(cell, batch, seed=77)
+    cot = np.random.default_rng(5).normal(size=(batch, 2))
+    dp = dev_params(params)
+    flat, la, ph = sysd.logpsi_vjp(dp, torch.as_tensor(x, device='cuda'), torch.as_tensor(cot, device='cuda'))
+    got = sysd.unpack_grad(flat, dp)
+    net = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    cc = torch.complex(torch.as_tensor(cot[:, 0]), torch.as_tensor(cot[:, 1]))
+    ref = otrain.logpsi_vjp(net.apply, params, torch.as_tensor(x), cc)
+    assert_tree_close(got, ref, 1e-9)
+    lp = torch.stack([net.apply(params, torch.as_tensor(xx)) for xx in x])
+    assert float((la.cpu() - lp.real).abs().max()) < 1e-10
+    assert float((torch.angle(ph.cpu() * torch.exp(-1j * lp.imag))).abs().max()) < 1e-10
+
+
+@pytest.mark.parametrize('name', ['lih', 'lih_twist', 'bcc_li', 'lih_fulldet', 'lih_tri'])
+def test_vjp_vs_reference_finite_differences(name):
+    """d/dh log psi(theta + h v) at h = 0 from the reference's own forward (tools/make_golden.py)."""
+    fx, cell, klist, net_kw, params = load_case(name)
+    sysd = system_for(cell, klist, net_kw)
+    v = make_test_direction(int(fx['gradfd_seed']), params)
+    dp = dev_params(params)
+    n = len(fx['gradfd_dlogabs'])
+    x = torch.as_tensor(fx['x'][:n], device='cuda')
+    for b in range(n):
+        for cot, key in (((1.0, 0.0), 'gradfd_dlogabs'), ((0.0, 1.0), 'gradfd_darg')):
+            c = torch.zeros(n, 2, dtype=torch.float64, device='cuda')
+            c[b] = torch.tensor(cot, dtype=torch.float64)
+            flat, _, _ = sysd.logpsi_vjp(dp, x, c)
+            got = tree_dot(sysd.unpack_grad(flat, dp), v)
+            assert abs(got - float(fx[key][b])) < 2e-7 * max(1.0, abs(float(fx[key][b]))), (b, key, got, fx[key][b])
+
+
+def test_vjp_groups_chunks_and_linearity():
+    """Batches that span several 80-walker groups, a ragged tail, several passes (small workspace)."""
+    fx, cell, klist, net_kw, params = load_case('lih')
+    sysd = system_for(cell, klist, net_kw)
+    B = 203
+    x = torch.as_tensor(systems.synthetic_walkers(cell, B, seed=3), device='cuda')
+    cot = torch.as_tensor(np.random.default_rng(9).normal(size=(B, 2)), device='cuda')
+    dp = dev_params(params)
+    full, la, _ = sysd.logpsi_vjp(dp, x, cot)
+    full = full.clone()
+    # the same call again: bit-identical (fixed reduction order, no atomics)
+    again, _, _ = sysd.logpsi_vjp(dp, x, cot)
+    assert torch.equal(full, again)
+    # one group per pass
+    one_group = int(sysd.lib.ds_vjp_workspace_bytes(sysd.handle, 1))
+    chunked, la2, _ = sysd.logpsi_vjp(dp, x, cot, max_bytes=one_group)
+    scale = float(full.abs().max())
+    assert float((chunked - full).abs().max()) < 1e-12 * scale
+    assert torch.equal(la, la2)
+    # linearity in the cotangent / additivity over walkers
+    parts = torch.zeros_like(full)
+    for lo, hi in ((0, 1), (1, 80), (80, 81), (81, 203)):
+        g, _, _ = sysd.logpsi_vjp(dp, x[lo:hi], cot[lo:hi])
+        parts += g
+    assert float((parts - full).abs().max()) < 1e-12 * scale
+    # against the oracle on a subset that crosses a group boundary
+    sel = slice(70, 90)
+    g, _, _ = sysd.logpsi_vjp(dp, x[sel], cot[sel])
+    net = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    ref = otrain.logpsi_vjp(net.apply, params, x[sel].cpu(), torch.view_as_complex(cot[sel].cpu().contiguous()))
+    assert_tree_close(sysd.unpack_grad(g, dp), ref, 1e-9)
+
+
+def test_vjp_zero_cotangent_and_empty_batch():
+    fx, cell, klist, net_kw, params = load_case('lih')
+    sysd = system_for(cell, klist, net_kw)
+    dp = dev_params(params)
+    x = torch.as_tensor(fx['x'], device='cuda')
+    g, _, _ = sysd.logpsi_vjp(dp, x, torch.zeros(x.shape[0], 2, dtype=torch.float64, device='cuda'))
+    assert float(g.abs().max()) == 0.0
+    g, la, ph = sysd.logpsi_vjp(dp, x[:0], torch.zeros(0, 2, dtype=torch.float64, device='cuda'))
+    assert g.shape == (sysd.param_count,) and float(g.abs().max()) == 0.0 and la.shape == (0,)
+
+
+@pytest.mark.parametrize('name', ['lih_bias', 'lih_lastlayer', 'lih_diagenv', 'lih_fullenv'])
+def test_vjp_unsupported_options_fail_loudly(name):
+    fx, cell, klist, net_kw, params = load_case(name)
+    sysd = system_for(cell, klist, net_kw)
+    x = torch.as_tensor(fx['x'], device='cuda')
+    with pytest.raises(RuntimeError, match='parameter gradient'):
+        sysd.logpsi_vjp(dev_params(params), x, torch.ones(x.shape[0], 2, dtype=torch.float64, device='cuda'))
+
+
+def test_vjp_float32():
+    fx, cell, klist, net_kw, params = load_case('lih')
+    s64, s32 = system_for(cell, klist, net_kw), system_for(cell, klist, net_kw, torch.float32)
+    x = systems.synthetic_walkers(cell, 90, seed=8)
+    cot = np.random.default_rng(2).normal(size=(90, 2))
+    p64, p32 = dev_params(params), dev_params(params, torch.float32)
+    g64, _, _ = s64.logpsi_vjp(p64, torch.as_tensor(x, device='cuda'), torch.as_tensor(cot, device='cuda'))
+    g32, _, _ = s32.logpsi_vjp(p32, torch.as_tensor(x, dtype=torch.float32, device='cuda'),
+                               torch.as_tensor(cot, dtype=torch.float32, device='cuda'))
+    t64, t32 = s64.unpack_grad(g64, p64), s32.unpack_grad(g32, p32)
+    for a, b in zip(leaves(t64), leaves(t32)):
+        assert float((a - b.double()).abs().max()) < 2e-3 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.parametrize('clip_type,clip', [('real', 5.0), ('real', 0.5), ('complex', 0.7), ('real', 0.0)])
+def test_energy_gradient_vs_oracle(clip_type, clip):
+    """total_energy.value_and_grad == jax.value_and_grad(total_energy) through the custom JVP (train.py:91-142)."""
+    from deepsolid_amd import network as dnet, train as dtrain
+    fx, cell, klist, net_kw, params = load_case('lih')
+    net = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    loss_fn = dtrain.make_loss(net.apply, None, cell, clip_local_energy=clip, clip_type=clip_type)
+    dp = dev_params(params)
+    x = torch.as_tensor(fx['x'], device='cuda')
+    (loss, aux), grads = loss_fn.value_and_grad(dp, x)
+    onet_ = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    oloss = otrain.make_loss(onet_.apply, cell, mode='hessian', clip_local_energy=clip, clip_type=clip_type)
+    (l_ref, aux_ref), g_ref = oloss.value_and_grad(params, torch.as_tensor(fx['x']))
+    assert abs(float(loss) - float(l_ref)) < 1e-8
+    assert float((aux.local_energy.cpu() - aux_ref.local_energy).abs().max()) < 1e-8
+    assert_tree_close(grads, g_ref, 1e-7)
+
+
+def test_training_step_runs_and_lowers_the_energy_estimate():
+    """train.make_training_step (train.py:147-184) with Adam: a few steps on LiH from a fixed seed."""
+    from deepsolid_amd import network as dnet, qmc, train as dtrain
+    fx, cell, klist, net_kw, params = load_case('lih')
+    net = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    slog = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', **net_kw)
+    B = 512
+    loss_fn = dtrain.make_loss(net.apply, None, cell, clip_local_energy=5.0, clip_type='real')
+    mcmc = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=5)
+    init, update = dtrain.adam(2e-3)
+    dp = dev_params(params)
+    state = init(dp)
+    step = dtrain.make_training_step(mcmc, loss_fn, update)
+    data = torch.as_tensor(systems.synthetic_walkers(cell, B, seed=1), device='cuda')
+    gen = torch.Generator(device='cuda'); gen.manual_seed(0)
+    before = [p.clone() for p in leaves(dp)]
+    losses = []
+    for t in range(12):
+        data, dp, state, loss, aux, pmove, g = step(t, data, dp, state, gen, 0.1)
+        assert np.isfinite(float(loss)) and 0.0 < float(pmove) <= 1.0
+        losses.append(float(loss))
+    assert any(not torch.equal(a, b) for a, b in zip(before, leaves(dp)))
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])

@@ -113,3 +113,38 @@ def test_poscar_reader_and_init_electrons(tmp_path):
     # spin-polarised request: one spin flipped somewhere
     x2 = init_guess.init_electrons(7, sim, sim.a, (4, 2), batch_size=4)
     assert x2.shape == (4, 18)
+
+
+@pytest.mark.parametrize('clip_type,clip', [('real', 5.0), ('real', 0.3), ('complex', 0.5), ('complex', 0.0)])
+def test_clip_difference_matches_oracle(clip_type, clip):
+    """train.py:105-129 (host logic of the energy gradient; single process, pmean = identity)."""
+    import torch
+    from deepsolid_amd import train as dtrain
+    from oracle import train as otrain
+    g = torch.Generator().manual_seed(4)
+    diff = torch.complex(torch.randn(64, generator=g, dtype=torch.float64), torch.randn(64, generator=g, dtype=torch.float64))
+    diff[3] *= 40.0
+    a, b = dtrain.clip_difference(diff, clip, clip_type), otrain.clip_difference(diff, clip, clip_type)
+    assert float((a - b).abs().max()) < 1e-13
+    if clip > 0 and clip < 1:
+        assert float((a - diff).abs().max()) > 0.1       # clipping active
+    with pytest.raises(ValueError, match='Unrecognized clip type'):
+        dtrain.clip_difference(diff, 1.0, 'nope')
+
+
+def test_adam_matches_torch_optim():
+    import torch
+    from deepsolid_amd import train as dtrain
+    g = torch.Generator().manual_seed(1)
+    params = {'a': [{'w': torch.randn(5, 3, generator=g, dtype=torch.float64)}], 'b': torch.randn(4, generator=g, dtype=torch.float64)}
+    ref = [params['a'][0]['w'].clone().requires_grad_(True), params['b'].clone().requires_grad_(True)]
+    opt = torch.optim.Adam(ref, lr=1e-2)
+    init, update = dtrain.adam(1e-2)
+    state = init(params)
+    for t in range(5):
+        grads = {'a': [{'w': torch.randn(5, 3, generator=g, dtype=torch.float64)}], 'b': torch.randn(4, generator=g, dtype=torch.float64)}
+        ref[0].grad, ref[1].grad = grads['a'][0]['w'].clone(), grads['b'].clone()
+        opt.step()
+        state, params = update(t, grads, params, state)
+    assert float((params['a'][0]['w'] - ref[0].detach()).abs().max()) < 1e-12
+    assert float((params['b'] - ref[1].detach()).abs().max()) < 1e-12

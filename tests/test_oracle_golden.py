@@ -131,3 +131,26 @@ def test_laplacian_modes_agree(name):
         assert abs(complex(ke) - ref) < 1e-10 * max(1.0, abs(ref)), m
     with pytest.raises(ValueError):
         oham.local_energy_seperate(net.apply, cell, mode='nope')
+
+
+@pytest.mark.parametrize('name', ['lih', 'lih_twist', 'bcc_li', 'lih_fulldet', 'lih_tri'])
+def test_oracle_parameter_gradient_vs_reference_finite_differences(name):
+    """torch autograd over the restated forward (oracle/train.py:logpsi_vjp) against the directional
+    derivative of the REFERENCE-executed forward along oracle.testing.make_test_direction."""
+    from oracle import train as otrain
+    from oracle.testing import make_test_direction
+    fx, cell, klist, net_kw, params = load_case(name)
+    net = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    v = make_test_direction(int(fx['gradfd_seed']), params)
+
+    def dot(t, d):
+        if isinstance(t, dict):
+            return sum(dot(t[k], d[k]) for k in t)
+        if isinstance(t, (list, tuple)):
+            return sum(dot(a, c) for a, c in zip(t, d))
+        return float((t * torch.as_tensor(d)).sum())
+    nb = 1 if name == 'bcc_li' else len(fx['gradfd_dlogabs'])
+    for b in range(nb):
+        for cot, key in ((1.0 + 0j, 'gradfd_dlogabs'), (1j, 'gradfd_darg')):
+            g = otrain.logpsi_vjp(net.apply, params, tt(fx['x'][b:b + 1]), torch.tensor([cot]))
+            assert abs(dot(g, v) - float(fx[key][b])) < 2e-7 * max(1.0, abs(float(fx[key][b])))

@@ -294,6 +294,22 @@ def main():
             h = case.get('fd_h', 2e-3)
             d.update(ke_fd=np.asarray([fd_kinetic(f, x[b], h=h) for b in range(nfd)]),
                      ke_fd_h=h, ke_fd_tol=case.get('fd_tol', 5e-6))
+        # --- parameter gradient: directional derivative of the reference-executed forward ----
+        ngf = case.get('gradfd_walkers', 0)
+        if ngf:
+            from oracle.testing import make_test_direction, tree_axpy
+            vdir = make_test_direction(case['seed'] + 500, params)
+            h = 2.5e-4
+            dl, da = [], []
+            for b in range(ngf):
+                vals = {}
+                for m in (-2, -1, 1, 2):
+                    vals[m] = nets['eval_phase_and_slogdet'].apply(tree_axpy(pnp, m * h, vdir), x[b])
+                d4 = lambda k: (-vals[2][k] + 8 * vals[1][k] - 8 * vals[-1][k] + vals[-2][k]) / (12 * h)
+                ph0 = complex(d['phase'][b])
+                dl.append(float(np.real(d4(1))))
+                da.append(float(np.imag(np.conj(ph0) * d4(0))))       # d arg = Im(conj(phase) d phase)
+            d.update(gradfd_dlogabs=np.asarray(dl), gradfd_darg=np.asarray(da), gradfd_h=h, gradfd_seed=case['seed'] + 500)
         path = os.path.join(out_dir, name + '.npz')
         np.savez_compressed(path, **d)
         print(name, 'N=%d' % N, 'NG=%d' % d['ewald_ng'], 'logabs', d['logabs'][:2],
