@@ -148,3 +148,93 @@ def test_adam_matches_torch_optim():
         state, params = update(t, grads, params, state)
     assert float((params['a'][0]['w'] - ref[0].detach()).abs().max()) < 1e-12
     assert float((params['b'] - ref[1].detach()).abs().max()) < 1e-12
+
+
+def test_training_step_averages_packed_gradient_over_two_ranks(tmp_path):
+    """train.make_training_step (train.py:147-184, search_direction pmean :176-177) with world_size 2 over
+    gloo: the per-rank packed gradient is averaged in one all-reduce, then unpacked; both ranks take the same
+    optimiser step.  The loss is a stub (no GPU here); the reduction / unpack / update plumbing is the product's."""
+    script = tmp_path / 'worker.py'
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from deepsolid_amd import train, constants
+dist.init_process_group('gloo')
+r = dist.get_rank()
+calls = []
+_orig = dist.all_reduce
+def counting(t, *a, **k):
+    calls.append(t.numel())
+    return _orig(t, *a, **k)
+dist.all_reduce = counting
+
+class StubSystem:
+    def unpack_grad(self, flat, params):
+        return {'w': flat[:6].reshape(2, 3), 'b': flat[6:8]}
+
+class StubLoss:
+    system = StubSystem()
+    def value_and_grad_packed(self, params, data):
+        flat = torch.arange(8, dtype=torch.float64) * (1.0 + r)          # rank-dependent gradient
+        return (torch.tensor(-1.0 - r), None), flat
+
+params = {'w': torch.zeros(2, 3, dtype=torch.float64), 'b': torch.zeros(2, dtype=torch.float64)}
+init, update = train.adam(0.1)
+state = init(params)
+mcmc = lambda p, d, key, w: (d, torch.tensor(0.5))
+step = train.make_training_step(mcmc, StubLoss(), update)
+data, params, state, loss, aux, pmove, g = step(0, torch.zeros(4, 12), params, state, 0, 0.1)
+assert calls == [8], calls                                                # ONE message for the whole gradient
+assert torch.allclose(g['w'].reshape(-1), torch.arange(6, dtype=torch.float64) * 1.5)
+assert torch.allclose(g['b'], torch.tensor([9.0, 10.5], dtype=torch.float64))
+both = [torch.zeros(2, 3, dtype=torch.float64) for _ in range(2)]
+dist.all_gather(both, params['w'])
+assert torch.equal(both[0], both[1])                                      # replicas stay in lock-step
+dist.destroy_process_group()
+print('rank', r, 'ok')
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                          '--master-addr', '127.0.0.1', '--master-port', '29537', str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('ok') == 2
+
+
+def test_checkpoint_reads_reference_layout_and_round_trips(tmp_path):
+    """A file written the way reference checkpoint.py:94-124 writes it (np.savez of t / data / pickled
+    params tree with a leading device axis / opt_state / mcmc_width) is read back; ours has the same layout."""
+    import torch
+    from deepsolid_amd import checkpoint
+    from oracle.testing import make_test_params
+    cell, _ = systems.build('lih')
+    params = make_test_params(3, cell.original_cell.atom_coords(), cell.nelec, dict(systems.DETNET_DEFAULTS))
+    ndev, bdev = 2, 5
+    rep = lambda a: np.broadcast_to(np.asarray(a), (ndev,) + np.asarray(a).shape).copy()
+    ref_params = {k: [{kk: rep(vv) for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    data = np.random.default_rng(0).normal(size=(ndev, bdev, 12))
+    fname = tmp_path / 'qmcjax_ckpt_000041.npz'
+    with open(fname, 'wb') as f:                         # the reference's writer, verbatim call shape
+        np.savez(f, t=41, data=data, params=ref_params, opt_state=None, mcmc_width=rep(0.03))
+    (tmp_path / 'qmcjax_ckpt_000099.npz').write_bytes(b'')                 # empty / corrupt files are skipped
+    (tmp_path / 'qmcjax_ckpt_000098.npz').write_bytes(b'corrupt')
+    assert checkpoint.find_last_checkpoint(str(tmp_path)) == str(fname)
+    with pytest.raises(ValueError, match='Incorrect number of devices'):
+        checkpoint.restore(str(fname), n_devices=1)
+    with pytest.raises(ValueError, match='Wrong batch size'):
+        checkpoint.restore(str(fname), batch_size=11, n_devices=2)
+    t, d, p, opt, width = checkpoint.restore(str(fname), batch_size=10, n_devices=2)
+    assert t == 42 and opt is None and d.shape == (2, 5, 12)
+    x, p1, w1 = checkpoint.to_single_device(d, p, width)
+    assert x.shape == (10, 12) and w1 == 0.03
+    np.testing.assert_array_equal(p1['single'][1]['w'], params['single'][1]['w'])
+    np.testing.assert_array_equal(p1['envelope'][0]['sigma'], params['envelope'][0]['sigma'])
+    # our writer -> same layout (device axis of 1), torch tensors accepted
+    tp = {k: [{kk: torch.as_tensor(vv) for kk, vv in dd.items()} for dd in v] for k, v in params.items()}
+    out = checkpoint.save(str(tmp_path), 7, torch.as_tensor(x), tp, None, torch.tensor(0.05))
+    assert os.path.basename(out) == 'qmcjax_ckpt_000007.npz'
+    t2, d2, p2, _, w2 = checkpoint.restore(out, batch_size=10)
+    assert t2 == 8 and d2.shape == (1, 10, 12) and p2['orbital'][0]['w'].shape == (1,) + params['orbital'][0]['w'].shape
+    _, p3, w3 = checkpoint.to_single_device(d2, p2, w2)
+    np.testing.assert_array_equal(p3['double'][0]['b'], params['double'][0]['b'])
+    assert abs(w3 - 0.05) < 1e-7
