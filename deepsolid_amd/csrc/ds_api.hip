@@ -722,7 +722,7 @@ struct GradPlan {
     size_t wlocT[DS_MAX_LAYERS], wshT[DS_MAX_LAYERS], worbT[2];
     int kpad[DS_MAX_LAYERS];         // rows of W * ZBAR per layer (Kloc rounded up to the GEMM's 64-feature blocks)
     size_t per_group;                // elements per group of PV walkers
-    size_t phi_off[2], phi_total, gbar, hb, h2;
+    size_t phi_off[2], phi_total, gbar, hb, h2, w2s;
 };
 
 int grad_plan(const ds_system* s, GradPlan* gp) {
@@ -750,9 +750,11 @@ int grad_plan(const ds_system* s, GradPlan* gp) {
     gp->gbar = (size_t)S.N * kpmax * PV;
     gp->hb = (size_t)S.N * h1max * PV;
     gp->h2 = (size_t)(PV / 5) * h2max * 5 * S.NP;
+    gp->w2s = (size_t)(PV / 5) * h2max * h2max;
     const WsLayout& v = s->wsv;
     gp->per_group = (size_t)(S.n_layers + 1) * v.G + (size_t)(S.n_double + 1) * gp->h2 + 3 * v.MEAN + v.ZB + 2 * v.Q + 2 * v.MOUT + v.DETS +
-                    2 * phi + (size_t)S.K * 2 * PV + gp->gbar + 3 * gp->hb + (size_t)h1max * PV + 3 * gp->h2 + (size_t)s->nparams;
+                    2 * phi + (size_t)S.K * 2 * PV + gp->gbar + 3 * gp->hb + (size_t)h1max * PV + 3 * gp->h2 + (size_t)s->nparams +
+                    gp->w2s;
     return 0;
 }
 
@@ -819,6 +821,7 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
         T* H2BAR[2]; H2BAR[0] = p; p += gp.h2 * ng; H2BAR[1] = p; p += gp.h2 * ng;
         T* Z2BAR = p; p += gp.h2 * ng;
         T* PART = p; p += np * ng;
+        T* W2S = p; p += gp.w2s * ng;       // split partials of the pair-stream weight gradients
         // ---- forward with every activation kept
         int rc = run_value_chain<T>(s, params, x, Bc, vb, st, out_logabs ? (T*)out_logabs + b0 : nullptr,
                                     out_phase ? (T*)out_phase + 2 * b0 : nullptr);
@@ -829,10 +832,14 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
                            s->ws.dets_off[1], cot + 2 * b0, (long)Bc, CW);
         const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
         auto outer = [&](const T* X, size_t xg, size_t xt, int ldx, const T* Z, size_t zg, size_t zt, int ldz, int nt, int J, int K,
-                         int Nc, size_t off) {
-            const int nwt = ((K + 31) / 32) * ((Nc + 31) / 32);
+                         int Nc, size_t off, int nsplit = 1) {
+            const int nwt = ((K + 31) / 32) * ((Nc + 31) / 32) * nsplit;
+            T* dst = nsplit == 1 ? PART + off : W2S;
             hipLaunchKernelGGL((ds::k_outer_gemm<T>), dim3((unsigned)((nwt + 3) / 4), (unsigned)ng), dim3(256), 0, st, X, xg, xt, ldx, Z, zg,
-                               zt, ldz, nt, J, K, Nc, PART + off, np);
+                               zt, ldz, nt, J, K, Nc, dst, nsplit == 1 ? np : (size_t)K * Nc, nsplit);
+            if (nsplit > 1)
+                hipLaunchKernelGGL((ds::k_reduce_splits<T>), dim3((unsigned)((K * Nc + 255) / 256), (unsigned)ng), dim3(256), 0, st, W2S,
+                                   nsplit, K * Nc, PART + off, np);
         };
         for (int sp = 0; sp < S.nch; ++sp) {
             const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
@@ -906,7 +913,7 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
                 (void)res2;
                 const int J = 5 * S.NP;
                 outer(vb.H2l[l], (size_t)(PV / 5) * K2 * J, (size_t)K2 * J, J, Z2BAR, (size_t)(PV / 5) * K2o * J, (size_t)K2o * J, J, PV / 5,
-                      J, K2, K2o, boff(s->i_w2[l]));
+                      J, K2, K2o, boff(s->i_w2[l]), PV / 5);
                 hipLaunchKernelGGL((ds::k_row_sums<T>), dim3(K2o, (unsigned)ng), dim3(256), 0, st, Z2BAR, (size_t)(PV / 5) * K2o * J,
                                    (size_t)K2o * J, J, PV / 5, J, PART + boff(s->i_b2[l]), np);
                 h2i ^= 1;

@@ -151,13 +151,18 @@ __global__ void __launch_bounds__(256) k_env_grad(SysDev<T> S, const T* __restri
 template <typename T>
 __global__ void __launch_bounds__(256) k_outer_gemm(const T* __restrict__ X, size_t x_group_stride, size_t x_tile_stride, int ldx,
                                                     const T* __restrict__ Z, size_t z_group_stride, size_t z_tile_stride, int ldz,
-                                                    int n_tiles, int J, int K, int Nc, T* __restrict__ part, size_t part_stride) {
+                                                    int n_tiles, int J, int K, int Nc, T* __restrict__ part, size_t part_stride,
+                                                    int nsplit) {
     typedef typename Acc4<T>::type acc_t;
     typedef T vec4 __attribute__((ext_vector_type(4)));
     const int g = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-    const int nbn = (Nc + 31) / 32, wt = blockIdx.x * 4 + wave;
+    // nsplit > 1: the tiles are dealt to nsplit waves per 32 x 32 block, each writing its own partial
+    // (part index g * nsplit + split) -- for small matrices with a long contraction (pair-stream weights)
+    const int nbn = (Nc + 31) / 32, nwt = ((K + 31) / 32) * nbn, wall = blockIdx.x * 4 + wave;
+    const int wt = wall % nwt, split = wall / nwt;
+    if (split >= nsplit) return;
     const int k0 = (wt / nbn) * 32, n0 = (wt % nbn) * 32;
-    if (k0 >= K) return;
+    const int tps = (n_tiles + nsplit - 1) / nsplit, t_lo = split * tps, t_hi = t_lo + tps < n_tiles ? t_lo + tps : n_tiles;
     const T* Xg = X + (size_t)g * x_group_stride;
     const T* Zg = Z + (size_t)g * z_group_stride;
     int kr[2], nr[2];
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(256) k_outer_gemm(const T* __restrict__ X, siz
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
     const vec4 zero = {0, 0, 0, 0};
-    for (int t = 0; t < n_tiles; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         const T* xa[2]; const T* zb[2];
         for (int a = 0; a < 2; ++a) {
             xa[a] = Xg + (size_t)t * x_tile_stride + (size_t)kr[a] * ldx + 4 * lq;
@@ -190,7 +195,7 @@ __global__ void __launch_bounds__(256) k_outer_gemm(const T* __restrict__ X, siz
                     for (int b = 0; b < 2; ++b) acc[a][b] = mfma16(av[a][s], bv[b][s], acc[a][b]);
         }
     }
-    T* out = part + (size_t)g * part_stride;
+    T* out = part + ((size_t)g * nsplit + split) * part_stride;
     for (int a = 0; a < 2; ++a)
         for (int r = 0; r < 4; ++r) {
             const int k = k0 + 16 * a + acc_row<T>(lane, r);
@@ -343,6 +348,16 @@ __global__ void __launch_bounds__(256) k_two_bwd(SysDev<T> S, const T* __restric
                 HBi[ib + (size_t)(k * 5 + c) * NP] = v;
             }
         }
+}
+
+// out[g][p] = sum_z scratch[g * nz + z][p]   (second stage of a split k_outer_gemm).  grid (ceil(n / 256), groups)
+template <typename T>
+__global__ void k_reduce_splits(const T* __restrict__ scratch, int nz, int n, T* __restrict__ part, size_t part_stride) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (p >= n) return;
+    T v = 0;
+    for (int z = 0; z < nz; ++z) v += scratch[((size_t)g * nz + z) * n + p];
+    part[(size_t)g * part_stride + p] = v;
 }
 
 // grad[p] = (accumulate ? grad[p] : 0) + sum_g part[g][p], groups in index order

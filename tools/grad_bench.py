@@ -1,5 +1,5 @@
 """Times the parameter-gradient pass (ds_logpsi_vjp) next to the value pass and the local energy.
-usage: python tools/grad_bench.py [system] [batch]"""
+usage: python tools/grad_bench.py [system] [batch] [vjp]"""
 import os
 import sys
 import time
@@ -34,6 +34,9 @@ def main():
             f()
         torch.cuda.synchronize()
         return (time.time() - t) / n * 1e3
+    if len(sys.argv) > 3 and sys.argv[3] == 'vjp':        # profiling: only the gradient pass
+        print(f'{name} B={B}: logpsi_vjp {timed(lambda: sysd.logpsi_vjp(dp, x, cot)):.2f} ms')
+        return
     t_val = timed(lambda: sysd.logpsi(dp, x))
     t_vjp = timed(lambda: sysd.logpsi_vjp(dp, x, cot))
     t_el = timed(lambda: sysd.local_energy(dp, x), 2)
