@@ -763,13 +763,18 @@ __global__ void __launch_bounds__(256) k_mfma_peak(long iters, double* out) {
     acc_t acc[NACC];
     for (int j = 0; j < NACC; ++j) acc[j] = acc_t{0, 0, 0, 0};
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    // shader-clock cycles (s_memtime) and constant-rate ticks (s_memrealtime) across the loop: their ratio is
+    // the core clock the MFMA pipe actually ran at
+    const long long c0 = clock64(), r0 = wall_clock64();
     for (long it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < NACC; ++j) acc[j] = mfma16(a, b, acc[j]);
     }
     double s = 0;
     for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    const long long c1 = clock64(), r1 = wall_clock64();
     if (s == 12345.678) out[0] = s;   // keep the chain alive
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { out[1] = (double)(c1 - c0); out[2] = (double)(r1 - r0); }
 }
 
 }  // namespace ds
