@@ -729,8 +729,6 @@ int grad_plan(const ds_system* s, GradPlan* gp) {
     const ds::SysDev<double>& S = s->sd;
     const size_t PV = ds::PV;
     if (s->use_last) return fail("parameter gradient: use_last_layer is not supported");
-    if (S.env_type != 0) return fail("parameter gradient: only the isotropic envelope is supported");
-    if (S.bias_orb) return fail("parameter gradient: bias_orbitals is not supported");
     if (S.n_double != S.n_layers - 1) return fail("parameter gradient: unexpected layer counts");
     size_t off = 0;
     int h1max = 0, h2max = 0, kpmax = S.h1[S.n_layers];
@@ -848,13 +846,16 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
             hipLaunchKernelGGL((ds::k_orbital_bwd<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, vb.PHI[sp], pgs, vb.Q, vb.MINV, V.MOUT,
                                V.mout_off[S.mat_ch[sp]], CW, sp, (long)Bc, S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, PB[sp], QBAR);
             outer(vb.Gl[L] + (size_t)i0 * S.ldk * PV, gws, gts, PV, PB[sp], pgs, (size_t)OC * PV, PV, ns, PV, Kl, OC, boff(s->i_worb[sp]));
+            if (S.bias_orb)
+                hipLaunchKernelGGL((ds::k_orb_bias_grad<T>), dim3(2 * S.nparam[sp], (unsigned)ng), dim3(256), 0, st, PB[sp], pgs, ns, OC,
+                                   S.nparam[sp], PART + boff(s->i_borb[sp]), np);
             dim3 block; unsigned gz;
             gemm_geom(Kl, 4, &block, &gz);
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, gz), block, 0, st, PB[sp], pgs, (size_t)OC * PV,
                                WT + gp.worbT[sp], OC, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, GBAR + (size_t)i0 * Kl * PV,
                                (size_t)S.N * Kl * PV, Kl, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
         }
-        hipLaunchKernelGGL((ds::k_env_grad<T>), dim3((unsigned)ng, S.nch), dim3(256), 0, st, S, x, (long)b0, (long)Bc, vb.Gl[0], QBAR,
+        hipLaunchKernelGGL((ds::k_env_grad<T>), dim3((unsigned)ng, S.nch), dim3(256), 0, st, S, x, (long)Bc, vb.Gl[0], QBAR,
                            blk(s->i_pi[0]), blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), PART, np,
                            (long)boff(s->i_pi[0]), (long)boff(s->i_sg[0]), (long)boff(s->i_pi[S.nch - 1]), (long)boff(s->i_sg[S.nch - 1]));
         // ---- layers, last to first

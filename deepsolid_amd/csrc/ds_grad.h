@@ -102,30 +102,41 @@ __global__ void __launch_bounds__(256) k_orbital_bwd(SysDev<T> S, const T* __res
     }
 }
 
-// Isotropic envelope parameters (network.py:335-337): q = e * exp(i k.x), e = sum_a pi[a,p] exp(-|sd_ia sigma[a,p]|)
-//   d pi[a,p]    = sum_{i,b} ge * exp(-r),   d sigma[a,p] = sum_{i,b} ge * pi * exp(-r) * (-sd * sign(sd * sigma)),
-//   ge = Re(QBAR * exp(i k.x)).     grid (groups, spin channels), block 256: a thread owns (a, p)
+// Envelope parameters (network.py:335-364): q = e * exp(i k.x), e = sum_a pi[a,p] exp(-r_a),
+//   isotropic r = |sd sigma[a,p]|;  diagonal r = |(sigma[a,m,p] rel_m)_m|;  full r = |(sum_k sigma[k,m,a,p] rel_k)_m|
+//   d pi[a,p] = sum_{i,b} ge exp(-r),   d sigma = sum_{i,b} ge pi exp(-r) (-dr/dsigma),   ge = Re(QBAR * exp(i k.x)).
+// grid (groups, spin channels), block 256: a thread owns ONE sigma entry (a, p, j), j < 1 / 3 / 9 (and pi[a,p] when j = 0)
 template <typename T>
-__global__ void __launch_bounds__(256) k_env_grad(SysDev<T> S, const T* __restrict__ x, long B0, long Bc, const T* __restrict__ G0,
+__global__ void __launch_bounds__(256) k_env_grad(SysDev<T> S, const T* __restrict__ x, long Bc, const T* __restrict__ G0,
                                                   const T* __restrict__ QBAR, const T* __restrict__ env_pi0,
                                                   const T* __restrict__ env_sg0, const T* __restrict__ env_pi1,
                                                   const T* __restrict__ env_sg1, T* __restrict__ part, size_t part_stride,
                                                   long off_pi0, long off_sg0, long off_pi1, long off_sg1) {
     const int g = blockIdx.x, sp = blockIdx.y, N = S.N, A = S.A;
     const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn, np = S.nparam[sp];
+    const int nsig = S.env_type == 0 ? 1 : (S.env_type == 1 ? 3 : 9);
     const T* pi_ = sp == 0 ? env_pi0 : env_pi1;
     const T* sg_ = sp == 0 ? env_sg0 : env_sg1;
     T* dpi = part + (size_t)g * part_stride + (sp == 0 ? off_pi0 : off_pi1);
     T* dsg = part + (size_t)g * part_stride + (sp == 0 ? off_sg0 : off_sg1);
-    (void)B0;
-    for (int idx = threadIdx.x; idx < A * np; idx += blockDim.x) {
-        const int a = idx / np, p = idx % np;
-        const T pv = pi_[idx], sv = sg_[idx];
+    for (int idx = threadIdx.x; idx < A * np * nsig; idx += blockDim.x) {
+        const int j = idx / (A * np), ap = idx % (A * np), a = ap / np, p = ap % np;
+        const int jk = j / 3, jm = j % 3;            // full: sigma[k = jk][m = jm];  diagonal: m = j
+        const T pv = pi_[ap];
+        // sigma entries feeding the three components u_m of this (a, p)
+        T s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0, s20 = 0, s21 = 0, s22 = 0;
+        if (S.env_type == 0) s00 = sg_[ap];
+        else if (S.env_type == 1) { s00 = sg_[(a * 3 + 0) * np + p]; s11 = sg_[(a * 3 + 1) * np + p]; s22 = sg_[(a * 3 + 2) * np + p]; }
+        else {
+            s00 = sg_[(0 * A + a) * np + p]; s01 = sg_[(1 * A + a) * np + p]; s02 = sg_[(2 * A + a) * np + p];
+            s10 = sg_[(3 * A + a) * np + p]; s11 = sg_[(4 * A + a) * np + p]; s12 = sg_[(5 * A + a) * np + p];
+            s20 = sg_[(6 * A + a) * np + p]; s21 = sg_[(7 * A + a) * np + p]; s22 = sg_[(8 * A + a) * np + p];
+        }
         const T* kv = S.klist[sp] + 3 * (p % S.norb[sp]);
         T gp = 0, gs = 0;
         for (int ii = 0; ii < ns; ++ii) {
             const int i = i0 + ii;
-            const T* sdp = G0 + ((size_t)(g * N + i) * S.ldk + S.nf * a) * PV;
+            const T* fp = G0 + ((size_t)(g * N + i) * S.ldk + S.nf * a) * PV;     // rows sd, rel_x, rel_y, rel_z of atom a
             const T* qb = QBAR + ((size_t)(g * N + i) * S.nparam_max + p) * 2 * PV;
             for (int c = 0; c < PV; ++c) {
                 const long wi = (long)g * PV + c;
@@ -134,13 +145,29 @@ __global__ void __launch_bounds__(256) k_env_grad(SysDev<T> S, const T* __restri
                 T sn, cs;
                 ds_sincos(kv[0] * xp[0] + kv[1] * xp[1] + kv[2] * xp[2], &sn, &cs);
                 const T ge = qb[c] * cs - qb[PV + c] * sn;
-                const T sd = sdp[c], u = sd * sv, ex = ds_exp(-ds_abs(u));
-                gp += ge * ex;
-                gs -= ge * pv * ex * sd * ds_sign(u);
+                if (S.env_type == 0) {
+                    const T sd = fp[c], u = sd * s00, ex = ds_exp(-ds_abs(u));
+                    gp += ge * ex;
+                    gs -= ge * pv * ex * sd * ds_sign(u);
+                } else {
+                    const T r0 = fp[(size_t)PV + c], r1 = fp[(size_t)2 * PV + c], r2 = fp[(size_t)3 * PV + c];
+                    // u_m = sum_k sigma[k][m] rel_k  (diagonal: only k = m)
+                    const T u0 = s00 * r0 + s10 * r1 + s20 * r2, u1 = s01 * r0 + s11 * r1 + s21 * r2, u2 = s02 * r0 + s12 * r1 + s22 * r2;
+                    const T r = ds_sqrt(u0 * u0 + u1 * u1 + u2 * u2), ex = ds_exp(-r);
+                    gp += ge * ex;
+                    if (r > T(0)) {
+                        const T um = jm == 0 ? u0 : (jm == 1 ? u1 : u2);
+                        const int kk = S.env_type == 1 ? jm : jk;
+                        const T rk = kk == 0 ? r0 : (kk == 1 ? r1 : r2);
+                        gs -= ge * pv * ex * um * rk / r;
+                    }
+                }
             }
         }
-        dpi[idx] = gp;
-        dsg[idx] = gs;
+        if (j == 0) dpi[ap] = gp;
+        if (S.env_type == 0) dsg[ap] = gs;
+        else if (S.env_type == 1) dsg[(a * 3 + jm) * np + p] = gs;
+        else dsg[(j * A + a) * np + p] = gs;
     }
 }
 
@@ -224,6 +251,25 @@ __global__ void __launch_bounds__(256) k_row_sums(const T* __restrict__ Z, size_
         __syncthreads();
     }
     if (threadIdx.x == 0) part[(size_t)g * part_stride + n] = red[0];
+}
+
+// orbital bias gradient (network.py:546 bias_orbitals): d b[part * nparam + p] = sum over electrons and walkers of the
+// packed column (p, part) of PHIBAR.  grid (2 * nparam, groups), block 256
+template <typename T>
+__global__ void __launch_bounds__(256) k_orb_bias_grad(const T* __restrict__ PHIBAR, size_t group_stride, int ns, int OC, int nparam,
+                                                       T* __restrict__ part, size_t part_stride) {
+    __shared__ T red[256];
+    const int q = blockIdx.x, g = blockIdx.y, p = q % nparam, pt = q / nparam;
+    const T* Pg = PHIBAR + (size_t)g * group_stride + (size_t)orb_col<T>(p, pt) * PV;
+    T v = 0;
+    for (int idx = threadIdx.x; idx < ns * PV; idx += blockDim.x) v += Pg[(size_t)(idx / PV) * OC * PV + idx % PV];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(size_t)g * part_stride + q] = red[0];
 }
 
 // MEAN[group][spin][k][PV] = mean over the spin's electrons of G rows (network.py:327-330)

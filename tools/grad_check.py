@@ -50,7 +50,9 @@ def main():
         net = oracle_net(cell, klist, net_kw, 'eval_logdet')
         cc = torch.complex(torch.as_tensor(cot[:, 0]), torch.as_tensor(cot[:, 1]))
         ref = otrain.logpsi_vjp(net.apply, params, torch.as_tensor(x), cc)
-        la_ref = torch.stack([net.apply(params, torch.as_tensor(xx)).real for xx in x])
+        from oracle.network import params_to_torch
+        pt = params_to_torch(params)
+        la_ref = torch.stack([net.apply(pt, torch.as_tensor(xx)).real for xx in x])
         print(f'== {name}  B={B}  hip {t1 - t0:.3f}s   logabs err {float((la.cpu() - la_ref).abs().max()):.2e}')
         worst = 0.0
         for (pa, g), (_, r) in zip(leaves(got), leaves(ref)):
