@@ -190,7 +190,10 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': 'k_jet_gemm<%s,4,5,2> (hidden one-electron layers: K=%d MFMA GEMM + fused tanh-jet epilogue)' % ('double' if dtype == torch.float64 else 'float', h1 + nch * h2),
                      'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                      'traffic': None, 'traffic_detail': None, 'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch,
-                     'flops_per_walker_layer': f_layer},
+                     'flops_per_walker_layer': f_layer,
+                     # issue-rate ceiling of the instruction the kernel uses, measured on this part
+                     # (tools/gpu_probe.py; profiles/r01_mfma_f64_probe.json, r01_mfma44_probe.txt); `frac` uses `peak`
+                     'instruction_ceiling': {'v_mfma_f64_16x16x4_f64': 51.5, 'unit': 'TFLOP/s'} if dtype == torch.float64 else None},
         'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},     # from one extra untimed step
     }
     if args.system == 'bcc_li' and dtype == torch.float64:
