@@ -236,13 +236,13 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 // Shared spin-mean term of a hidden layer, S[n][slot] = sum_sp sum_k W_sh[sp*Kh + k][n] * mean_{i in sp} G[i][k][slot]
 // (network.py:327-330: the tiled spin means of h_one), with the means formed on the fly:
 // a workgroup (one walker, NW waves of 16*NB features) sums the n_s electron rows of a 16-row K chunk into
-// LDS (each thread owns KC*P/threads elements, fully coalesced), then every wave runs 4 k-steps on it.
+// LDS (each thread sums 32-byte pieces of the rows, fully coalesced), then every wave runs 4 k-steps on it.
 template <typename T, int NB, int ST>
 __global__ void __launch_bounds__(1024 / NB, (NB == 4 ? 2 : 1))
 k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, int Kh, T* __restrict__ Sb, int Nout, int P) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int KC = 16;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    extern __shared__ __attribute__((aligned(32))) char smem_raw[];
     T* mbuf = reinterpret_cast<T*>(smem_raw);            // [2][KC][P]
     const int w = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lq = lane >> 4, n0 = (blockIdx.z * (nthr >> 6) + wave) * 16 * NB;
@@ -259,11 +259,12 @@ k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, i
         const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn;
         const T inv = T(1) / T(ns);
         const T* g0 = Gw + ((size_t)i0 * S.ldk + k0) * P;
-        for (int e = tid; e < KC * P; e += nthr) {
-            T v = 0;
+        typedef T vec4 __attribute__((ext_vector_type(4)));          // P is a multiple of 16: every row is 128-byte aligned
+        for (int e = tid; e < KC * P / 4; e += nthr) {
+            vec4 v = {0, 0, 0, 0};
 #pragma unroll 4
-            for (int i = 0; i < ns; ++i) v += g0[(size_t)i * S.ldk * P + e];
-            dst[e] = v * inv;
+            for (int i = 0; i < ns; ++i) v += *reinterpret_cast<const vec4*>(g0 + (size_t)i * S.ldk * P + 4 * e);
+            *reinterpret_cast<vec4*>(dst + 4 * e) = v * inv;
         }
     };
     fill(0, mbuf);
