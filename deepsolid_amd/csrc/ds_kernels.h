@@ -215,18 +215,29 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
     __syncthreads();
     // h2[j][e] depends on r = x_j - x_e: d/dx_j = +d/dr, d/dx_e = -d/dr
     T* Ge = G + ((size_t)(w * N + e) * S.ldk + row0) * P;
-    for (int idx = tid; idx < S.nch * K2 * P; idx += nt) {
-        const int slot = idx % P, k = (idx / P) % K2, s = idx / (P * K2);
+    // a thread produces four consecutive slots of one row (32-byte store; one division per four elements)
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    const int QP = P / 4;
+    for (int idx = tid; idx < S.nch * K2 * QP; idx += nt) {
+        const int row = idx / QP, sq = idx - row * QP, k = row % K2, s = row / K2;
         const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
-        T v = 0;
-        if (slot == 0) v = sums[(s * K2 + k) * 5 + 0];
-        else if (slot == 1) v = sums[(s * K2 + k) * 5 + 4];
-        else if (slot < S.D) {
-            const int j = (slot - 2) / 3, c = (slot - 2) % 3;
-            if (j == e) v = -sums[(s * K2 + k) * 5 + 1 + c];
-            else if (j >= j0 && j < j0 + ns) v = hs[(k * 5 + 1 + c) * N + j] / T(ns);
+        const T inv = T(1) / T(ns);
+        const T* sm = sums + (s * K2 + k) * 5;
+        vec4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int slot = 4 * sq + u;
+            T x = 0;
+            if (slot == 0) x = sm[0];
+            else if (slot == 1) x = sm[4];
+            else if (slot < S.D) {
+                const int j = (slot - 2) / 3, c = (slot - 2) - 3 * j;
+                if (j == e) x = -sm[1 + c];
+                else if (j >= j0 && j < j0 + ns) x = hs[(k * 5 + 1 + c) * N + j] * inv;
+            }
+            v[u] = x;
         }
-        Ge[idx] = v;
+        *reinterpret_cast<vec4*>(Ge + (size_t)row * P + 4 * sq) = v;
     }
 }
 
