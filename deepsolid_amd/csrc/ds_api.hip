@@ -722,17 +722,21 @@ struct GradPlan {
     size_t wlocT[DS_MAX_LAYERS], wshT[DS_MAX_LAYERS], worbT[2];
     int kpad[DS_MAX_LAYERS];         // rows of W * ZBAR per layer (Kloc rounded up to the GEMM's 64-feature blocks)
     size_t per_group;                // elements per group of PV walkers
-    size_t phi_off[2], phi_total, gbar, hb, h2, w2s;
+    size_t phi_off[2], phi_total, gbar, hb, h2, w2s, sbar, wshorbT[2];
+    int korb, korb_pad;                // rows of the orbital-head input (with use_last_layer: h | pair means) and padded
 };
 
 int grad_plan(const ds_system* s, GradPlan* gp) {
     const ds::SysDev<double>& S = s->sd;
     const size_t PV = ds::PV;
-    if (s->use_last) return fail("parameter gradient: use_last_layer is not supported");
-    if (S.n_double != S.n_layers - 1) return fail("parameter gradient: unexpected layer counts");
+    if (S.n_double != (s->use_last ? S.n_layers : S.n_layers - 1)) return fail("parameter gradient: unexpected layer counts");
     size_t off = 0;
-    int h1max = 0, h2max = 0, kpmax = S.h1[S.n_layers];
+    int h1max = 0, h2max = 0, ocmax = 0;
     for (int l = 0; l <= S.n_layers; ++l) { h1max = std::max(h1max, S.h1[l]); h2max = std::max(h2max, S.h2[l]); }
+    const int Kl = S.h1[S.n_layers];
+    gp->korb = Kl + (s->use_last ? S.nch * S.h2[S.n_layers] : 0);
+    gp->korb_pad = s->use_last ? rup(gp->korb, 64) : Kl;
+    int kpmax = gp->korb_pad;
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], Nout = S.h1[l + 1], Kloc = Kh + S.nch * S.h2[l];
         gp->kpad[l] = rup(Kloc, 64);
@@ -740,7 +744,11 @@ int grad_plan(const ds_system* s, GradPlan* gp) {
         gp->wshT[l] = off; if (l > 0) off += (size_t)Nout * S.nch * Kh;
         if (l > 0) kpmax = std::max(kpmax, gp->kpad[l]);
     }
-    for (int c = 0; c < S.nch; ++c) { gp->worbT[c] = off; off += (size_t)S.ocols[c] * S.h1[S.n_layers]; }
+    for (int c = 0; c < S.nch; ++c) {
+        gp->worbT[c] = off; off += (size_t)S.ocols[c] * gp->korb_pad;
+        gp->wshorbT[c] = off; if (s->use_last) off += (size_t)S.ocols[c] * S.nch * Kl;
+        ocmax = std::max(ocmax, S.ocols[c]);
+    }
     gp->wt_total = rup((int)off, 16);
     size_t phi = 0;
     for (int c = 0; c < S.nch; ++c) { gp->phi_off[c] = phi; phi += (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * PV; }
@@ -749,10 +757,11 @@ int grad_plan(const ds_system* s, GradPlan* gp) {
     gp->hb = (size_t)S.N * h1max * PV;
     gp->h2 = (size_t)(PV / 5) * h2max * 5 * S.NP;
     gp->w2s = (size_t)(PV / 5) * h2max * h2max;
+    gp->sbar = (size_t)std::max(h1max, ocmax) * PV;
     const WsLayout& v = s->wsv;
     gp->per_group = (size_t)(S.n_layers + 1) * v.G + (size_t)(S.n_double + 1) * gp->h2 + 3 * v.MEAN + v.ZB + 2 * v.Q + 2 * v.MOUT + v.DETS +
-                    2 * phi + (size_t)S.K * 2 * PV + gp->gbar + 3 * gp->hb + (size_t)h1max * PV + 3 * gp->h2 + (size_t)s->nparams +
-                    gp->w2s;
+                    2 * phi + (size_t)S.K * 2 * PV + gp->gbar + 3 * gp->hb + gp->sbar + 3 * gp->h2 + (size_t)s->nparams +
+                    gp->w2s + (s->use_last ? v.MEAN + (size_t)S.nch * ocmax * PV : 0);
     return 0;
 }
 
@@ -782,7 +791,10 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
         transpose(blk(s->i_wloc[l]), Kloc, Nout, WT + gp.wlocT[l], gp.kpad[l]);
         transpose(blk(s->i_wsh[l]), S.nch * Kh, Nout, WT + gp.wshT[l], S.nch * Kh);
     }
-    for (int c = 0; c < S.nch; ++c) transpose(blk(s->i_worb[c]), Kl, S.ocols[c], WT + gp.worbT[c], Kl);
+    for (int c = 0; c < S.nch; ++c) {
+        transpose(blk(s->i_worb[c]), gp.korb, S.ocols[c], WT + gp.worbT[c], gp.korb_pad);
+        if (s->use_last) transpose(blk(s->i_wsh_orb[c]), S.nch * Kl, S.ocols[c], WT + gp.wshorbT[c], S.nch * Kl);
+    }
     const size_t np = (size_t)s->nparams;
     const WsLayout& V = s->wsv;
     int h1max = 0;
@@ -815,11 +827,16 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
         T* GBAR = p; p += gp.gbar * ng;
         T* HB[2]; HB[0] = p; p += gp.hb * ng; HB[1] = p; p += gp.hb * ng;
         T* ZBAR = p; p += gp.hb * ng;
-        T* SBAR = p; p += (size_t)h1max * PV * ng;
+        T* SBAR = p; p += gp.sbar * ng;
         T* H2BAR[2]; H2BAR[0] = p; p += gp.h2 * ng; H2BAR[1] = p; p += gp.h2 * ng;
         T* Z2BAR = p; p += gp.h2 * ng;
         T* PART = p; p += np * ng;
         T* W2S = p; p += gp.w2s * ng;       // split partials of the pair-stream weight gradients
+        T* MEANBAR2 = nullptr;
+        if (s->use_last) {
+            MEANBAR2 = p; p += V.MEAN * ng;
+            for (int c = 0; c < S.nch; ++c) { vb.SORB[c] = p; p += (size_t)S.ocols[c] * PV * ng; }
+        }
         // ---- forward with every activation kept
         int rc = run_value_chain<T>(s, params, x, Bc, vb, st, out_logabs ? (T*)out_logabs + b0 : nullptr,
                                     out_phase ? (T*)out_phase + 2 * b0 : nullptr);
@@ -844,32 +861,52 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
             const size_t pgs = (size_t)ns * OC * PV;
             HIP_OK(hipMemsetAsync(PB[sp], 0, pgs * ng * sizeof(T), st));
             hipLaunchKernelGGL((ds::k_orbital_bwd<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, vb.PHI[sp], pgs, vb.Q, vb.MINV, V.MOUT,
-                               V.mout_off[S.mat_ch[sp]], CW, sp, (long)Bc, S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, PB[sp], QBAR);
-            outer(vb.Gl[L] + (size_t)i0 * S.ldk * PV, gws, gts, PV, PB[sp], pgs, (size_t)OC * PV, PV, ns, PV, Kl, OC, boff(s->i_worb[sp]));
+                               V.mout_off[S.mat_ch[sp]], CW, sp, (long)Bc, S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr,
+                               s->use_last ? (const T*)vb.SORB[sp] : (const T*)nullptr, PB[sp], QBAR);
+            outer(vb.Gl[L] + (size_t)i0 * S.ldk * PV, gws, gts, PV, PB[sp], pgs, (size_t)OC * PV, PV, ns, PV, gp.korb, OC, boff(s->i_worb[sp]));
             if (S.bias_orb)
                 hipLaunchKernelGGL((ds::k_orb_bias_grad<T>), dim3(2 * S.nparam[sp], (unsigned)ng), dim3(256), 0, st, PB[sp], pgs, ns, OC,
                                    S.nparam[sp], PART + boff(s->i_borb[sp]), np);
+            const int Kop = gp.korb_pad;
             dim3 block; unsigned gz;
-            gemm_geom(Kl, 4, &block, &gz);
+            gemm_geom(Kop, 4, &block, &gz);
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, gz), block, 0, st, PB[sp], pgs, (size_t)OC * PV,
-                               WT + gp.worbT[sp], OC, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, GBAR + (size_t)i0 * Kl * PV,
-                               (size_t)S.N * Kl * PV, Kl, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                               WT + gp.worbT[sp], OC, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, GBAR + (size_t)i0 * Kop * PV,
+                               (size_t)S.N * Kop * PV, Kop, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+            if (s->use_last) {
+                // shared term of the orbital head (network.py:535): S_orb = W_sh^T mean_i h_i, one per spin channel
+                const int Ksh = S.nch * Kl;
+                if (sp == 0)
+                    hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)((Ksh * PV + 255) / 256), (unsigned)ng), dim3(256), 0, st, S, vb.Gl[L],
+                                       Kl, MEANL);
+                hipLaunchKernelGGL((ds::k_sum_tiles<T>), dim3((unsigned)((OC * PV + 255) / 256), (unsigned)ng), dim3(256), 0, st, PB[sp], pgs, ns,
+                                   OC * PV, SBAR);
+                outer(MEANL, (size_t)Ksh * PV, 0, PV, SBAR, (size_t)OC * PV, 0, PV, 1, PV, Ksh, OC, boff(s->i_wsh_orb[sp]));
+                gemm_geom(Ksh, 4, &block, &gz);
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
+                                   (const T*)nullptr, 0, SBAR, (size_t)OC * PV, WT + gp.wshorbT[sp], OC, 0, sp == 0 ? MEANBAR : MEANBAR2,
+                                   (size_t)Ksh * PV, Ksh, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+            }
         }
         hipLaunchKernelGGL((ds::k_env_grad<T>), dim3((unsigned)ng, S.nch), dim3(256), 0, st, S, x, (long)Bc, vb.Gl[0], QBAR,
                            blk(s->i_pi[0]), blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), PART, np,
                            (long)boff(s->i_pi[0]), (long)boff(s->i_sg[0]), (long)boff(s->i_pi[S.nch - 1]), (long)boff(s->i_sg[S.nch - 1]));
         // ---- layers, last to first
-        const T* D1 = GBAR; int ld1 = Kl; const T* MB = nullptr; const T* CARRY = nullptr;
+        const T* D1 = GBAR; int ld1 = gp.korb_pad; const T* MB = s->use_last ? MEANBAR : nullptr; const T* CARRY = nullptr;
+        const T* MB2 = s->use_last && S.nch > 1 ? MEANBAR2 : nullptr;
         int hbi = 0, h2i = 0;
+        if (s->use_last)       // the last level of the pair stream feeds the orbital head only
+            hipLaunchKernelGGL((ds::k_pair_scatter<T>), dim3((S.NP + 255) / 256, S.h2[L] * 5, (unsigned)(ng * (PV / 5))), dim3(256), 0, st, S, GBAR,
+                               gp.korb_pad, Kl, S.h2[L], H2BAR[h2i]);
         for (int l = L - 1; l >= 0; --l) {
             const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1], Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
             const bool res = Kh == Nout;
             T* HBc = HB[hbi];
             if (res)
-                hipLaunchKernelGGL((ds::k_layer_bwd_prep<T, true>), dim3(Nout / 4, (unsigned)ng), dim3(4 * PV), 0, st, S, D1, ld1, MB, CARRY,
+                hipLaunchKernelGGL((ds::k_layer_bwd_prep<T, true>), dim3(Nout / 4, (unsigned)ng), dim3(4 * PV), 0, st, S, D1, ld1, MB, MB2, CARRY,
                                    vb.Gl[l + 1], vb.Gl[l], Nout, HBc, ZBAR, SBAR, PART + boff(s->i_b[l]), np);
             else
-                hipLaunchKernelGGL((ds::k_layer_bwd_prep<T, false>), dim3(Nout / 4, (unsigned)ng), dim3(4 * PV), 0, st, S, D1, ld1, MB, CARRY,
+                hipLaunchKernelGGL((ds::k_layer_bwd_prep<T, false>), dim3(Nout / 4, (unsigned)ng), dim3(4 * PV), 0, st, S, D1, ld1, MB, MB2, CARRY,
                                    vb.Gl[l + 1], vb.Gl[l], Nout, HBc, ZBAR, SBAR, PART + boff(s->i_b[l]), np);
             outer(vb.Gl[l], gws, gts, PV, ZBAR, (size_t)S.N * Nout * PV, (size_t)Nout * PV, PV, S.N, PV, Kloc, Nout, boff(s->i_wloc[l]));
             const T* MEANl = vb.MEAN0;
@@ -919,7 +956,7 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
                                    (size_t)K2o * J, J, PV / 5, J, PART + boff(s->i_b2[l]), np);
                 h2i ^= 1;
             }
-            D1 = GBAR; ld1 = Kpad; MB = MEANBAR; CARRY = res ? HBc : nullptr;
+            D1 = GBAR; ld1 = Kpad; MB = MEANBAR; MB2 = nullptr; CARRY = res ? HBc : nullptr;
             hbi ^= 1;
         }
         hipLaunchKernelGGL((ds::k_reduce_partials<T>), dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, PART, np, (long)ng, (long)np,

@@ -71,7 +71,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_orbital_bwd(SysDev<T> S, const T* __restrict__ PHI, size_t phi_group_stride,
                                                      const T* __restrict__ Q, const T* __restrict__ MINV, size_t minv_stride,
                                                      size_t minv_off, const T* __restrict__ CW, int sp, long Bc,
-                                                     const T* __restrict__ bias, T* __restrict__ PHIBAR, T* __restrict__ QBAR) {
+                                                     const T* __restrict__ bias, const T* __restrict__ Sb, T* __restrict__ PHIBAR,
+                                                     T* __restrict__ QBAR) {
     const int ii = blockIdx.x, g = blockIdx.y, N = S.N, OC = S.ocols[sp];
     const int i0 = sp == 0 ? 0 : S.n_up, nparam = S.nparam[sp], i = i0 + ii;
     const int norb = S.norb[sp], n = S.det_n[S.mat_ch[sp]], row = S.row_off[sp] + ii;
@@ -90,6 +91,7 @@ __global__ void __launch_bounds__(256) k_orbital_bwd(SysDev<T> S, const T* __res
             const T* mi = Iw + ((size_t)kdet * n * n + (size_t)m * n + row) * 2 * PV + c;
             const Cx<T> A = Cx<T>(Cw[(size_t)(2 * kdet) * PV + c], Cw[(size_t)(2 * kdet + 1) * PV + c]) * Cx<T>(mi[0], mi[PV]);
             Cx<T> phi(Pw[(size_t)cr * PV + c], Pw[(size_t)ci * PV + c]);
+            if (Sb) { phi.re += Sb[((size_t)g * OC + cr) * PV + c]; phi.im += Sb[((size_t)g * OC + ci) * PV + c]; }   // use_last_layer
             if (bias) { phi.re += bias[p]; phi.im += bias[nparam + p]; }
             const Cx<T> q(Qw[(size_t)(p * 2) * PV + c], Qw[(size_t)(p * 2 + 1) * PV + c]);
             a = A * q;
@@ -272,6 +274,16 @@ __global__ void __launch_bounds__(256) k_orb_bias_grad(const T* __restrict__ PHI
     if (threadIdx.x == 0) part[(size_t)g * part_stride + q] = red[0];
 }
 
+// out[group][col][PV] = sum over the tiles (electrons) of in[group][tile][col][PV]: cotangent of a shared term
+template <typename T>
+__global__ void k_sum_tiles(const T* __restrict__ in, size_t group_stride, int n_tiles, int n, T* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (idx >= n) return;
+    T v = 0;
+    for (int t = 0; t < n_tiles; ++t) v += in[(size_t)g * group_stride + (size_t)t * n + idx];
+    out[(size_t)g * n + idx] = v;
+}
+
 // MEAN[group][spin][k][PV] = mean over the spin's electrons of G rows (network.py:327-330)
 template <typename T>
 __global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restrict__ G, int Kh, T* __restrict__ MEAN) {
@@ -287,13 +299,15 @@ __global__ void __launch_bounds__(256) k_spin_mean(SysDev<T> S, const T* __restr
 }
 
 // One-electron layer, element-wise part of the reverse sweep (network.py:517-528):
-//   hbar = D1[e][n] (W * ZBAR of the layer above, or of the orbital head) + MB[spin(e)][n] / n_spin (its spin-mean rows)
+//   hbar = D1[e][n] (W * ZBAR of the layer above, or of the orbital head) + MB[spin(e)][n] / n_spin (its spin-mean rows;
+//          MB2: second contribution, the other spin's orbital head with use_last_layer)
 //          + CARRY[e][n] / sqrt2 (residual bypass of the layer above)
 //   HB = hbar;   y = tanh(z) recovered from the stored activations;   ZBAR = (RES ? hbar / sqrt2 : hbar) * (1 - y^2)
 //   SBAR[n] = sum_e ZBAR[e][n];   bias partial[n] = sum_{e,c} ZBAR
 // grid (Nout / 4, groups), block 4 * PV: thread (n, c) walks the electrons.
 template <typename T, bool RES>
 __global__ void __launch_bounds__(4 * PV) k_layer_bwd_prep(SysDev<T> S, const T* __restrict__ D1, int ld1, const T* __restrict__ MB,
+                                                           const T* __restrict__ MB2,
                                                            const T* __restrict__ CARRY, const T* __restrict__ Gout,
                                                            const T* __restrict__ Gin, int Nout, T* __restrict__ HB,
                                                            T* __restrict__ ZBAR, T* __restrict__ SBAR, T* __restrict__ part,
@@ -306,6 +320,7 @@ __global__ void __launch_bounds__(4 * PV) k_layer_bwd_prep(SysDev<T> S, const T*
         const int sp = spin_of(e, S.n_up);
         T hb = D1[((size_t)(g * N + e) * ld1 + n) * PV + c];
         if (MB) hb += MB[((size_t)(g * S.nch + sp) * Nout + n) * PV + c] / T(sp == 0 ? S.n_up : S.n_dn);
+        if (MB2) hb += MB2[((size_t)(g * S.nch + sp) * Nout + n) * PV + c] / T(sp == 0 ? S.n_up : S.n_dn);
         if (CARRY) hb += CARRY[((size_t)(g * N + e) * Nout + n) * PV + c] * rs2;
         HB[((size_t)(g * N + e) * Nout + n) * PV + c] = hb;
         const T ho = Gout[((size_t)(g * N + e) * S.ldk + n) * PV + c];

@@ -135,8 +135,8 @@ int ds_logpsi_grad(ds_system* sys, const void* params, const void* x, int64_t B,
  * the result is  tangents_dot = mean(Re(clip_diff * conj(d log psi)))  for every parameter direction, i.e.
  * the energy gradient jax.value_and_grad(total_energy) returns (train.py:147-176, process.py:226-228).
  * cot (B, 2); grad (ds_param_count(),) in the packed layout of ds_param_layout, overwritten (padding entries
- * are zero); out_logabs / out_phase optional.  All network options except use_last_layer = 1 (which returns
- * an error here and runs in every other entry point).  Weight gradients are reduced over
+ * are zero); out_logabs / out_phase optional.  Every network option of ds_system_desc is supported.
+ * Weight gradients are reduced over
  * walkers in a fixed order (no atomics): the result is bit-reproducible run to run. */
 int64_t ds_vjp_workspace_bytes(const ds_system* sys, int64_t B);
 int ds_logpsi_vjp(ds_system* sys, const void* params, const void* x, int64_t B, const void* cot, void* grad,

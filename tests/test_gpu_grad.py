@@ -52,7 +52,7 @@ def assert_tree_close(got, ref, rtol):
 
 
 @pytest.mark.parametrize('name,batch', [('h2', 5), ('lih', 7), ('lih_twist', 4), ('lih_2x1x1', 3), ('bcc_li', 5),
-                                        ('lih_fulldet', 4), ('lih_tri', 4), ('lih_bias', 4), ('lih_diagenv', 4), ('lih_fullenv', 4),
+                                        ('lih_fulldet', 4), ('lih_tri', 4), ('lih_bias', 4), ('lih_diagenv', 4), ('lih_fullenv', 4), ('lih_lastlayer', 4),
                                         ('lih_fn_defaults', 3), ('bcc_li_fulldet', 2), ('graphene', 2)])
 def test_vjp_vs_oracle_autograd(name, batch):
     fx, cell, klist, net_kw, params = load_case(name)
@@ -133,15 +133,6 @@ def test_vjp_zero_cotangent_and_empty_batch():
     assert float(g.abs().max()) == 0.0
     g, la, ph = sysd.logpsi_vjp(dp, x[:0], torch.zeros(0, 2, dtype=torch.float64, device='cuda'))
     assert g.shape == (sysd.param_count,) and float(g.abs().max()) == 0.0 and la.shape == (0,)
-
-
-@pytest.mark.parametrize('name', ['lih_lastlayer'])
-def test_vjp_unsupported_options_fail_loudly(name):
-    fx, cell, klist, net_kw, params = load_case(name)
-    sysd = system_for(cell, klist, net_kw)
-    x = torch.as_tensor(fx['x'], device='cuda')
-    with pytest.raises(RuntimeError, match='parameter gradient'):
-        sysd.logpsi_vjp(dev_params(params), x, torch.ones(x.shape[0], 2, dtype=torch.float64, device='cuda'))
 
 
 def test_vjp_float32():
