@@ -14,6 +14,18 @@ template <int CTRL> __device__ __forceinline__ double dpp_row(double x) {
 
 constexpr int NB = 4, ST = 5;
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void kstep_vec(const double (&a)[NB], const double (&b)[ST], v4d (&acc)[NB][ST]) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const double r1 = dpp_row<0x12C>(a[i]), r2 = dpp_row<0x128>(a[i]), r3 = dpp_row<0x124>(a[i]);
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            M44(a[i], b[s], acc[i][s][0]); M44(r1, b[s], acc[i][s][1]); M44(r2, b[s], acc[i][s][2]); M44(r3, b[s], acc[i][s][3]);
+        }
+    }
+}
+
 template <int SCHED>
 __device__ __forceinline__ void kstep(const double (&a)[NB], const double (&b)[ST], double (&acc)[NB][ST][4]) {
 #pragma unroll
@@ -72,6 +84,39 @@ __global__ void __launch_bounds__(256, 2) k_loop(long iters, const double* __res
     if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) out[1] = (double)(c1 - c0);
 }
 
+// same loop with the accumulators held as 4-vectors (8 consecutive VGPRs per 16x16 tile), as the GEMM kernel holds them
+template <int ASTR, int BSTR>
+__global__ void __launch_bounds__(256, 2) k_loop_vec(long iters, const double* __restrict__ src, double* out) {
+    v4d acc[NB][ST];
+    for (int i = 0; i < NB; ++i) for (int s = 0; s < ST; ++s) acc[i][s] = v4d{0, 0, 0, 0};
+    double a0[NB], b0[ST], a1[NB], b1[ST];
+    // lane (lr, lq) reads row lq (ASTR / BSTR doubles apart), 16 consecutive doubles per row and tile: the GEMM's operand pattern
+    const int lr = threadIdx.x & 15, lq = (threadIdx.x >> 4) & 3;
+    const double* pa = src + (blockIdx.x & 7) * 4096 + lq * ASTR + lr;
+    const double* pb = src + 65536 + (blockIdx.x & 7) * 4096 + lq * BSTR + lr;
+    for (int i = 0; i < NB; ++i) { a0[i] = pa[16 * i]; a1[i] = pa[4 * ASTR + 16 * i]; }
+    for (int s = 0; s < ST; ++s) { b0[s] = pb[16 * s]; b1[s] = pb[4 * BSTR + 16 * s]; }
+    const long long c0 = clock64();
+    for (long it = 0; it < iters; it += 2) {
+        double a2[NB], b2[ST], a3[NB], b3[ST];
+        { const int k = (it + 2) & 14;
+          for (int i = 0; i < NB; ++i) a2[i] = pa[(size_t)4 * k * ASTR + 16 * i];
+          for (int s = 0; s < ST; ++s) b2[s] = pb[(size_t)4 * k * BSTR + 16 * s]; }
+        kstep_vec(a0, b0, acc);
+        { const int k = (it + 3) & 15;
+          for (int i = 0; i < NB; ++i) a3[i] = pa[(size_t)4 * k * ASTR + 16 * i];
+          for (int s = 0; s < ST; ++s) b3[s] = pb[(size_t)4 * k * BSTR + 16 * s]; }
+        kstep_vec(a1, b1, acc);
+        for (int i = 0; i < NB; ++i) { a0[i] = a2[i]; a1[i] = a3[i]; }
+        for (int s = 0; s < ST; ++s) { b0[s] = b2[s]; b1[s] = b3[s]; }
+    }
+    const long long c1 = clock64();
+    double sum = 0;
+    for (int i = 0; i < NB; ++i) for (int s = 0; s < ST; ++s) for (int t = 0; t < 4; ++t) sum += acc[i][s][t];
+    if (sum == 12345.678) out[0] = sum;
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) out[1] = (double)(c1 - c0);
+}
+
 template <int LOADS, int SCHED> void run(const char* name, const double* src, double* out) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -91,10 +136,18 @@ template <int LOADS, int SCHED> void run(const char* name, const double* src, do
 
 int main() {
     double *src, *out;
-    hipMalloc(&src, 64 * 1024 * 8 + 65536); hipMemset(src, 0, 64 * 1024 * 8 + 65536); hipMalloc(&out, 128);
+    hipMalloc(&src, 4 << 20); hipMemset(src, 0, 4 << 20); hipMalloc(&out, 128);
     run<0, 0>("invariant operands, compiler schedule", src, out);
     run<0, 1>("invariant operands, forced interleave", src, out);
     run<1, 0>("prefetched loads, compiler schedule", src, out);
     run<1, 1>("prefetched loads, forced interleave", src, out);
+    {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const long iters = 20000;
+        float ms;
+#define RUNV(A, B) for (int rep = 0; rep < 2; ++rep) { hipEventRecord(e0, 0); hipLaunchKernelGGL((k_loop_vec<A, B>), 512, 256, 0, 0, iters, src, out); hipEventRecord(e1, 0); hipEventSynchronize(e1); } \
+        hipEventElapsedTime(&ms, e0, e1); printf("vector accumulators, rot A, row strides A %4d B %4d doubles: %6.2f TFLOP/s\n", A, B, 512.0 * 4 * iters * NB * ST * 2048 / (ms * 1e-3) / 1e12);
+        RUNV(16, 16) RUNV(256, 80) RUNV(256, 16) RUNV(16, 80) RUNV(64, 64)
+    }
     return 0;
 }
