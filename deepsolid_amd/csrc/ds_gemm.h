@@ -190,46 +190,57 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         const T* Gi = X + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
         T* Go = Z + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
         const int base = lane & 48;
+        // the rows of the epilogue are independent: the S / residual / bias loads of row q + DEPTH are requested
+        // before row q is worked on, so their latency (L2 for S, HBM for the residual) overlaps the arithmetic
+        constexpr int NQ = NB * 4, DEPTH = 2;
+        T zq[DEPTH + 1][ST], hq[DEPTH + 1][ST], bq[DEPTH + 1];
+        auto fetch = [&](int q, int slot) {
+            const int n = n0 + 16 * (q >> 2) + acc_row<T>(lane, q & 3);
 #pragma unroll
-        for (int a = 0; a < NB; ++a)
+            for (int s = 0; s < ST; ++s) zq[slot][s] = Sp[(size_t)n * P + 16 * s];
+            if (EPI == 2 || EPI == 4) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + 16 * a + acc_row<T>(lane, r);
-                T z[ST], hv[ST];
-                T ss = 0;
+                for (int s = 0; s < ST; ++s) hq[slot][s] = Gi[(size_t)n * P + 16 * s];
+            }
+            bq[slot] = bias[n];
+        };
 #pragma unroll
-                for (int s = 0; s < ST; ++s) z[s] = Sp[(size_t)n * P + 16 * s];
-                if (EPI == 2 || EPI == 4) {
+        for (int q = 0; q < DEPTH && q < NQ; ++q) fetch(q, q % (DEPTH + 1));
 #pragma unroll
-                    for (int s = 0; s < ST; ++s) hv[s] = Gi[(size_t)n * P + 16 * s];
-                }
-                const T bn = bias[n];
-                if (EPI >= 3) {
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) {
-                        T o = ds_tanh(z[s] + acc[a][s][r] + bn);
-                        if (EPI == 4) o = (hv[s] + o) * rs2;
-                        Go[(size_t)n * P + 16 * s] = o;
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int s = 0; s < ST; ++s) {
-                    z[s] += acc[a][s][r];
-                    if (16 * s + lr >= 2) ss += z[s] * z[s];
-                }
-                if (lr == 0) z[0] += bn;
-                ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
-                const T z0 = __shfl(z[0], base), zL = __shfl(z[0], base | 1);
-                const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
+        for (int q = 0; q < NQ; ++q) {
+            if (q + DEPTH < NQ) fetch(q + DEPTH, (q + DEPTH) % (DEPTH + 1));
+            const int a = q >> 2, r = q & 3, cur = q % (DEPTH + 1);
+            const int n = n0 + 16 * a + acc_row<T>(lane, r);
+            T(&z)[ST] = zq[cur];
+            T(&hv)[ST] = hq[cur];
+            const T bn = bq[cur];
+            T ss = 0;
+            if (EPI >= 3) {
 #pragma unroll
                 for (int s = 0; s < ST; ++s) {
-                    T o = d1 * z[s];
-                    if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
-                    if (EPI == 2) o = (hv[s] + o) * rs2;
+                    T o = ds_tanh(z[s] + acc[a][s][r] + bn);
+                    if (EPI == 4) o = (hv[s] + o) * rs2;
                     Go[(size_t)n * P + 16 * s] = o;
                 }
+                continue;
             }
+#pragma unroll
+            for (int s = 0; s < ST; ++s) {
+                z[s] += acc[a][s][r];
+                if (16 * s + lr >= 2) ss += z[s] * z[s];
+            }
+            if (lr == 0) z[0] += bn;
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+            const T z0 = __shfl(z[0], base), zL = __shfl(z[0], base | 1);
+            const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
+#pragma unroll
+            for (int s = 0; s < ST; ++s) {
+                T o = d1 * z[s];
+                if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
+                if (EPI == 2) o = (hv[s] + o) * rs2;
+                Go[(size_t)n * P + 16 * s] = o;
+            }
+        }
     }
 }
 
