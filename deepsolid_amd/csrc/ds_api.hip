@@ -292,8 +292,8 @@ template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
 }
 
 // workgroup size and grid.z of k_jet_gemm<NB>: at most 1024/NB threads (= its launch bound) per workgroup
-inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz) {
-    const int nw = Nout / (16 * NB), wmax = NB == 3 ? 4 : 1024 / NB / 64;
+inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz, int ST = 0) {
+    const int nw = Nout / (16 * NB), wmax = (NB == 3 || ST > 10) ? 4 : 1024 / NB / 64;
     int wpb = nw < wmax ? nw : wmax;
     // prefer a multiple of 4 waves per workgroup that divides the wave count: every SIMD then holds the same
     // number of waves (a SIMD with a single wave reaches only 3/4 of the MFMA issue rate)
@@ -366,7 +366,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             dim3 block; unsigned gz;
-            gemm_geom(Nout, NB, &block, &gz);
+            gemm_geom(Nout, NB, &block, &gz, ST);
             const size_t gws = (size_t)S.N * S.ldk * S.P, gts = (size_t)S.ldk * S.P;
             {
                 // shared spin-mean term S (one tile per walker): layer 0 from the MEAN buffer of k_features,
@@ -414,7 +414,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             dim3 block; unsigned gz;
-            gemm_geom(OC, NB, &block, &gz);
+            gemm_geom(OC, NB, &block, &gz, ST);
             if (s->use_last) {
                 ProfScope ps(s, DS_PROF_SHARED_TERM, st);
                 hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, gz), block, 2 * 16 * S.P * sizeof(T), st, S, c.G[gi],
@@ -463,14 +463,19 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                            L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,        \
                            L.dets_off[sp]);                                                                                    \
     } while (0)
-        // matrix-core version when the real expansion (2n) is a whole number of k-steps and one slot tile of Y fits LDS
-        const size_t ybytes = (size_t)n * 2 * n * 16 * sizeof(T) + 256 * sizeof(ds::Cx<T>);
+        // matrix-core version when the real expansion (2n) is a whole number of k-steps and a slot tile (or half of one) of Y fits LDS
+        const size_t ybytes16 = (size_t)n * 2 * n * 16 * sizeof(T) + 256 * sizeof(ds::Cx<T>);
+        const size_t ybytes8 = (size_t)n * 2 * n * 8 * sizeof(T) + 256 * sizeof(ds::Cx<T>);
         const int nt = (2 * n + 15) / 16;
-        if ((2 * n) % 4 == 0 && ybytes <= 150 * 1024 && nt <= 4 && !getenv("DS_DET_VALU")) {
-#define DS_TRM(NTV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV>), dim3(S.K, (unsigned)Bc), dim3(256), ybytes, st, S, c.MOUT, L.MOUT,  \
-                                       L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
-                                       L.dets_off[sp])
-            if (nt == 1) DS_TRM(1); else if (nt == 2) DS_TRM(2); else if (nt == 3) DS_TRM(3); else DS_TRM(4);
+        const bool sw8 = ybytes16 > 150 * 1024;
+        const size_t ybytes = sw8 ? ybytes8 : ybytes16;
+        if ((2 * n) % 4 == 0 && ybytes <= 150 * 1024 && nt <= 6 && !getenv("DS_DET_VALU")) {
+#define DS_TRM(NTV, SWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV>), dim3(S.K, (unsigned)Bc), dim3(256), ybytes, st, S, c.MOUT, L.MOUT,  \
+                                            L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
+                                            L.dets_off[sp])
+            if (sw8) { if (nt <= 4) DS_TRM(4, 8); else DS_TRM(6, 8); }
+            else if (nt == 1) DS_TRM(1, 16); else if (nt == 2) DS_TRM(2, 16); else if (nt == 3) DS_TRM(3, 16); else if (nt == 4) DS_TRM(4, 16);
+            else DS_TRM(6, 16);
 #undef DS_TRM
         } else
         if (n <= 16) DS_TRACE(16, 16);

@@ -468,19 +468,22 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
 //     tiles; the four waves split the electrons, park Y of one slot tile in LDS, then all threads form
 //     tr Y_d and sum_{i,e} Y_d[i][e] Y_d[e][i] with conflict-free LDS reads.
 // =====================================================================================
-template <typename T, int NT>
+// SW = slots of a 16-slot MFMA tile parked in LDS per pass: 16, or 8 (two passes over the tile, the products are
+// recomputed) when n * 2n * 16 elements do not fit the LDS.
+template <typename T, int NT, int SW>
 __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                         int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                         T* __restrict__ TR, size_t tr_stride, size_t tr_off,
                                                         T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int KSMAX = 4 * NT;                         // 2n <= 16 NT  ->  2n / 4 <= 4 NT k-steps
+    constexpr int NG = 256 / SW;                          // thread groups of the trace phase
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int P = S.P, n = S.det_n[ch], n2 = 2 * n, nks = n2 / 4;
-    T* Y = reinterpret_cast<T*>(smem_raw);               // [n][2n][16]
-    Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)n * n2 * 16);   // [256]
+    T* Y = reinterpret_cast<T*>(smem_raw);               // [n][2n][SW]
+    Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)n * n2 * SW);   // [256]
     const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
     const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
     T* Tw = TR + (size_t)w * tr_stride + tr_off + (size_t)kdet * 2 * P;
@@ -500,8 +503,9 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
             af[nt][ks] = v;
         }
     Cx<T> y2(0, 0);
-    const int d = tid & 15, g = tid >> 4;
-    for (int st = 0; st < P / 16; ++st) {
+    const int d = tid % SW, g = tid / SW;
+    for (int sp = 0; sp < (P / 16) * (16 / SW); ++sp) {
+        const int st = sp / (16 / SW), half = sp % (16 / SW);
         for (int i = wave; i < n; i += 4) {
             acc_t acc[NT];
 #pragma unroll
@@ -515,32 +519,43 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
                     for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(af[nt][ks], b, acc[nt]);
                 }
             }
+            if (SW == 16 || (lr / SW) == half) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int np = 16 * nt + acc_row<T>(lane, r);
-                    if (np < n2) Y[((size_t)i * n2 + np) * 16 + lr] = acc[nt][r];
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int np = 16 * nt + acc_row<T>(lane, r);
+                        if (np < n2) Y[((size_t)i * n2 + np) * SW + lr % SW] = acc[nt][r];
+                    }
+            }
         }
         __syncthreads();
-        const int slot = 16 * st + d;
+        const int slot = 16 * st + SW * half + d;
         const bool live = slot >= 1 && slot < S.D;
         Cx<T> trc(0, 0);
-        for (int pi = g; pi < n * n; pi += 16) {
-            const int i = pi / n, e = pi % n;
-            const Cx<T> yie(Y[((size_t)i * n2 + 2 * e) * 16 + d], Y[((size_t)i * n2 + 2 * e + 1) * 16 + d]);
+        // sum_{i,e} Y[i][e] Y[e][i] = sum_i Y[i][i]^2 + 2 sum_{i<e} Y[i][e] Y[e][i]: upper triangle only.  Rows r and
+        // n-1-r together hold n+1 entries (n even); odd n walks the full square.
+        const bool tri = (n & 1) == 0;
+        const int npair = tri ? (n / 2) * (n + 1) : n * n;
+        for (int pi = g; pi < npair; pi += NG) {
+            int i, e;
+            if (tri) {
+                const int r = pi / (n + 1), t = pi - r * (n + 1);
+                if (t < n - r) { i = r; e = r + t; } else { i = n - 1 - r; e = i + (t - (n - r)); }
+            } else { i = pi / n; e = pi - i * n; }
+            const Cx<T> yie(Y[((size_t)i * n2 + 2 * e) * SW + d], Y[((size_t)i * n2 + 2 * e + 1) * SW + d]);
             if (i == e) trc = trc + yie;
             if (slot >= 2) {
-                const Cx<T> yei(Y[((size_t)e * n2 + 2 * i) * 16 + d], Y[((size_t)e * n2 + 2 * i + 1) * 16 + d]);
-                y2 = cx_fma(yie, yei, y2);
+                const Cx<T> yei(Y[((size_t)e * n2 + 2 * i) * SW + d], Y[((size_t)e * n2 + 2 * i + 1) * SW + d]);
+                const T wgt = (tri && i != e) ? T(2) : T(1);
+                y2 = cx_fma(wgt * yie, yei, y2);
             }
         }
         red[tid] = trc;
         __syncthreads();
         if (g == 0 && live) {
             Cx<T> t(0, 0);
-            for (int q = 0; q < 16; ++q) t = t + red[q * 16 + d];
+            for (int q = 0; q < NG; ++q) t = t + red[q * SW + d];
             Tw[slot] = t.re;
             Tw[P + slot] = t.im;
         }
