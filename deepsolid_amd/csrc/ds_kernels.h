@@ -506,17 +506,18 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
     const int d = tid % SW, g = tid / SW;
     for (int sp = 0; sp < (P / 16) * (16 / SW); ++sp) {
         const int st = sp / (16 / SW), half = sp % (16 / SW);
-        // B operands of the wave's next electron row are requested before the current row's MFMAs (large matrices run one
+        // B operands of the wave's next two electron rows are requested before the current row's MFMAs (large matrices run one
         // workgroup per CU: nothing else hides the HBM latency)
-        T bc[KSMAX], bn[KSMAX];
+        T bc[KSMAX], bn[KSMAX], bm[KSMAX];
         auto load_row = [&](T (&b)[KSMAX], int i) {
             const T* xp = Mw + ((size_t)st * n * n2 + (size_t)i * n2 + lq) * 16 + lr;      // contiguous n*2n*16 chunk per slot tile
 #pragma unroll
             for (int ks = 0; ks < KSMAX; ++ks) b[ks] = ks < nks ? xp[(size_t)(4 * ks) * 16] : T(0);
         };
         if (wave < n) load_row(bc, wave);
+        if (wave + 4 < n) load_row(bn, wave + 4);
         for (int i = wave; i < n; i += 4) {
-            if (i + 4 < n) load_row(bn, i + 4);
+            if (i + 8 < n) load_row(bm, i + 8);
             acc_t acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = acc_t{0, 0, 0, 0};
@@ -528,7 +529,7 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
                 }
             }
 #pragma unroll
-            for (int ks = 0; ks < KSMAX; ++ks) bc[ks] = bn[ks];
+            for (int ks = 0; ks < KSMAX; ++ks) { bc[ks] = bn[ks]; bn[ks] = bm[ks]; }
             if (SW == 16 || (lr / SW) == half) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
