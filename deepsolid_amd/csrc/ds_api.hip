@@ -376,9 +376,13 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
                                        (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[0], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
                                        c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
-                else
-                    hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, gz), block, 2 * 16 * S.P * sizeof(T), st, S,
+                else {
+                    // (its own geometry: as many waves per workgroup as possible, every workgroup re-forms the spin means)
+                    dim3 sblock; unsigned sgz;
+                    gemm_geom(Nout, NB, &sblock, &sgz);
+                    hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, sgz), sblock, 2 * 16 * S.P * sizeof(T), st, S,
                                        c.G[gi], blk(s->i_wsh[l]), Kh, c.ZB, Nout, S.P);
+                }
             }
             {
                 // ... then the N electron tiles with the fused epilogue

@@ -250,7 +250,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 // a workgroup (one walker, NW waves of 16*NB features) sums the n_s electron rows of a 16-row K chunk into
 // LDS (each thread sums 32-byte pieces of the rows, fully coalesced), then every wave runs 4 k-steps on it.
 template <typename T, int NB, int ST>
-__global__ void __launch_bounds__((ST > 10 ? 256 : 1024 / NB), (NB == 4 ? 2 : 1))
+__global__ void __launch_bounds__(1024 / NB, (NB == 4 ? 2 : 1))
 k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, int Kh, T* __restrict__ Sb, int Nout, int P) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int KC = 16;
