@@ -1,5 +1,5 @@
 set -x
-mkdir -p gpurun_out/final
+mkdir -p gpurun_out/final gpurun_out/r01b
 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
 tail -c 600 gpurun_out/final/bench.json
 bash tools/profile_bench.sh r01b > gpurun_out/final/prof.txt 2>&1
