@@ -1,3 +1,6 @@
+#!/bin/bash
+# Round-end measurement batch (run on the GPU box from the repo root): bench lines, rocprofv3 kernel stats, PMC traffic,
+# gradient / value-chain profiles.  Results land in gpurun_out/; copy what should be judged into profiles/.
 set -x
 mkdir -p gpurun_out/final gpurun_out/r01b
 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
