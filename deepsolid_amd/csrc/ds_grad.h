@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) k_pair_scatter(SysDev<T> S, const T* __re
 //   z2bar[n] = (RES ? hb[n] / sqrt2 : hb[n]) * (1 - y[n]^2)         written to Z2BAR (for dW2 / db2)
 //   DX: H2BAR_in[k] = sum_n W[k][n] z2bar[n]  (MFMA, B operand formed on the fly)  + RES hb[k] / sqrt2 + pair-mean scatter
 template <typename T, int NTI, int NTO, bool RES, bool DX>
-__global__ void __launch_bounds__(256) k_two_bwd(SysDev<T> S, const T* __restrict__ HBn, const T* __restrict__ Hout,
+__global__ void __launch_bounds__(256, 3) k_two_bwd(SysDev<T> S, const T* __restrict__ HBn, const T* __restrict__ Hout,
                                                  const T* __restrict__ Hin, const T* __restrict__ W, const T* __restrict__ GB, int ldg,
                                                  int row0, T* __restrict__ Z2BAR, T* __restrict__ HBi) {
     typedef typename Acc4<T>::type acc_t;

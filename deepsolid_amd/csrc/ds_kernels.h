@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
 //     same lane, so the tanh chain rule is lane-local.
 // =====================================================================================
 template <typename T, int NT2, bool RES, bool VAL>
-__global__ void __launch_bounds__(256) k_two_layer(SysDev<T> S, const T* __restrict__ Hin, int Kin, const T* __restrict__ W,
+__global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __restrict__ Hin, int Kin, const T* __restrict__ W,
                                                    const T* __restrict__ bias, T* __restrict__ Hout) {
     typedef typename Acc4<T>::type acc_t;
     const int w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
