@@ -1,4 +1,4 @@
-"""Energy evaluation of a fixed wavefunction: the `optimizer='none'` branch of the reference driver
+"""Driver loops.  `run_inference`: energy evaluation of a fixed wavefunction, the `optimizer='none'` branch of the reference driver
 (reference DeepSolid/process.py:256-374), i.e. burn-in, then per iteration
 ``mcmc_step -> total_energy -> one CSV row -> MCMC width adaptation``.
 
@@ -87,3 +87,60 @@ def run_inference(slog_net, logdet_net, params, data, simulation_cell, iteration
         if writer:
             writer.__exit__(None, None, None)
     return data, width, rows
+
+
+def learning_rate_schedule(rate=5e-2, decay=1.0, delay=10000.0):
+    """process.py:200-202 with the defaults of base_config.py:46-51."""
+    return lambda t: rate * (1.0 / (1.0 + t / delay)) ** decay
+
+
+def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations, key=0, move_width=0.02, mcmc_steps=10,
+                 burn_in=100, adapt_frequency=100, learning_rate=None, clip_local_energy=5.0, clip_type='real',
+                 save_path=None, save_every=None, stats_file_name='train_stats', laplacian_mode='for',
+                 partition_number=3, t_init=0, opt_state=None):
+    """The `optimizer='adam'` branch of the reference driver (process.py:204-219, 256-383): burn-in, then per iteration
+    ``mcmc_step -> value_and_grad(total_energy) -> gradient pmean -> Adam -> CSV row -> width adaptation``, with
+    checkpoints in the reference's layout (`deepsolid_amd.checkpoint.save`) every `save_every` iterations.
+    `params` is updated in place.  Returns (data, params, opt_state, mcmc_width, rows)."""
+    from . import checkpoint
+    gen = key if isinstance(key, torch.Generator) else torch.Generator(device=data.device).manual_seed(int(key))
+    batch = data.shape[0]
+    mcmc_step = qmc.make_mcmc_step(slog_net.apply, batch, latvec=simulation_cell.a, steps=mcmc_steps)
+    total_energy = train.make_loss(logdet_net.apply, None, simulation_cell, clip_local_energy=clip_local_energy,
+                                   clip_type=clip_type, mode=laplacian_mode, partition_number=partition_number)
+    opt_init, opt_update = train.adam(learning_rate if learning_rate is not None else learning_rate_schedule())
+    if opt_state is None:
+        opt_state = opt_init(params)
+    step = train.make_training_step(mcmc_step, total_energy, opt_update)
+    width = float(move_width)
+    for _ in range(burn_in):
+        data, _ = mcmc_step(params, data, gen, width)
+    scale = float(getattr(simulation_cell, 'scale', 1))
+    pmoves = np.zeros(adapt_frequency)
+    rows = []
+    writer = Writer(stats_file_name, TRAIN_SCHEMA, save_path) if save_path else None
+    if writer:
+        writer.__enter__()
+    try:
+        for t in range(t_init, t_init + iterations):
+            data, params, opt_state, loss, aux, pmove, _ = step(t, data, params, opt_state, gen, width)
+            row = {'step': t, 'energy': float(loss) / scale, 'variance': float(aux.variance) / scale ** 2,
+                   'pmove': float(pmove), 'imaginary': float(aux.imaginary) / scale,
+                   'kinetic': complex(aux.kinetic.mean().item()) / scale, 'ewald': float(aux.ewald.mean()) / scale}
+            rows.append(row)
+            if writer:
+                writer.write(t, **row)
+            if t > 0 and t % adapt_frequency == 0:                       # process.py:368-373
+                if np.mean(pmoves) > 0.55:
+                    width *= 1.1
+                if np.mean(pmoves) < 0.5:
+                    width /= 1.1
+                pmoves[:] = 0
+            pmoves[t % adapt_frequency] = float(pmove)
+            if save_path and save_every and (t + 1) % save_every == 0:
+                checkpoint.save(save_path, t, data, params, None, width)
+    finally:
+        if writer:
+            writer.__exit__(None, None, None)
+    return data, params, opt_state, width, rows
+

@@ -190,3 +190,28 @@ def test_training_step_runs_and_lowers_the_energy_estimate():
         losses.append(float(loss))
     assert any(not torch.equal(a, b) for a, b in zip(before, leaves(dp)))
     assert np.mean(losses[-3:]) < np.mean(losses[:3])
+
+
+def test_training_loop_writes_stats_and_reference_checkpoints(tmp_path):
+    """inference.run_training (process.py:204-383, Adam branch): CSV rows in the reference schema, checkpoints that
+    `checkpoint.restore` (reference layout) reads back, parameters updated in place."""
+    from deepsolid_amd import checkpoint, inference, network as dnet
+    fx, cell, klist, net_kw, params = load_case('lih')
+    logdet = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    slog = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', **net_kw)
+    dp = dev_params(params)
+    w0 = dp['single'][0]['w'].clone()
+    data = torch.as_tensor(systems.synthetic_walkers(cell, 256, seed=4), device='cuda')
+    data, dp2, state, width, rows = inference.run_training(slog, logdet, dp, data, cell, iterations=6, key=3, burn_in=5,
+                                                           mcmc_steps=4, learning_rate=1e-3, save_path=str(tmp_path),
+                                                           save_every=3)
+    assert len(rows) == 6 and all(np.isfinite(r['energy']) for r in rows)
+    assert not torch.equal(w0, dp['single'][0]['w'])
+    lines = open(tmp_path / 'train_stats.csv').read().strip().splitlines()
+    assert lines[0] == 'step,energy,variance,pmove,imaginary,kinetic,ewald' and len(lines) == 7
+    last = checkpoint.find_last_checkpoint(str(tmp_path))
+    assert last.endswith('qmcjax_ckpt_000005.npz')
+    t, d, p, opt, w = checkpoint.restore(last, batch_size=256)
+    x, p1, w1 = checkpoint.to_single_device(d, p, w)
+    assert t == 6 and x.shape == (256, 12)
+    np.testing.assert_array_equal(p1['single'][0]['w'], dp['single'][0]['w'].cpu().numpy())
