@@ -11,7 +11,8 @@ noise ``(normals, uniforms)`` can be supplied instead for reproducible tests.
 All three samplers of the reference are available: all-electron Metropolis
 (``mh_update``, the default), one-electron moves (``mh_one_electron_update``) and
 drift-biased importance sampling (``importance_update``; the latter two are
-flagged "untested" in base_config.py:122-126).
+flagged "untested" in base_config.py:122-126), plus the asymmetric ``atoms=`` proposal
+of ``mh_update`` (qmc.py:197-215).
 """
 import torch
 
@@ -45,14 +46,48 @@ def limdrift(g, cutoff=1):
     return (cutoff * g / normalize[:, None]).reshape(shape)
 
 
+def _harmonic_mean(x, atoms):
+    """qmc.py:45-60: harmonic mean of each electron's (non-periodic) distances to the nuclei; x (B, N, 1, 3)."""
+    r_ae = torch.linalg.norm(x - atoms[None, ...], dim=-1, keepdim=True)
+    return 1.0 / torch.mean(1.0 / r_ae, dim=-2, keepdim=True)
+
+
+def _log_prob_gaussian(x, mu, sigma):
+    """qmc.py:26-42."""
+    return torch.sum(-0.5 * ((x - mu) ** 2) / (sigma ** 2), dim=(1, 2, 3)) - x.shape[-1] * torch.sum(torch.log(sigma), dim=(1, 2, 3))
+
+
+def _mh_update_asymmetric(params, f, x1, key, lp_1, num_accepts, latvec, stddev, atoms, normal, uniform):
+    """qmc.py:197-215: proposal width scaled per electron by the harmonic mean of its nuclear distances, with the
+    forward / reverse proposal densities in the acceptance ratio.  The wavefunction and the wrap run in the HIP
+    chain; the per-electron scale factors are a few element-wise tensor operations on the device."""
+    system = f.system
+    atoms = torch.as_tensor(atoms, dtype=x1.dtype, device=x1.device).reshape(-1, 3)
+    n = x1.shape[0]
+    normal, uniform = _noise(key, x1, lp_1, normal, uniform)
+    x1r = x1.reshape(n, -1, 1, 3)
+    hmean1 = _harmonic_mean(x1r, atoms)                                          # :200
+    x2 = (x1r + stddev * hmean1 * normal.reshape(x1r.shape)).reshape(n, -1)      # :202-203
+    x2, _ = distance.enforce_pbc(latvec if latvec is not None else system.cell.a, x2.contiguous())   # :204
+    lp_2 = 2.0 * f(params, x2)                                                   # :205
+    x2r = x2.reshape(n, -1, 1, 3)
+    hmean2 = _harmonic_mean(x2r, atoms)                                          # :208
+    lq_1 = _log_prob_gaussian(x1r, x2r, stddev * hmean1)                         # :210
+    lq_2 = _log_prob_gaussian(x2r, x1r, stddev * hmean2)                         # :211
+    cond = (lp_2 + lq_2 - lp_1 - lq_1) > torch.log(uniform)                      # :212, :218-219
+    x_new = torch.where(cond[:, None], x2, x1)
+    lp_new = torch.where(cond, lp_2, lp_1)
+    num_accepts += cond.sum().to(num_accepts.dtype)
+    return x_new, key, lp_new, num_accepts
+
+
 def mh_update(params, f, x1, key, lp_1, num_accepts, latvec=None, stddev=0.02, atoms=None, i=0,
               normal=None, uniform=None):
-    """One all-electron Metropolis step (qmc.py:153-224, symmetric branch).
+    """One all-electron Metropolis step (qmc.py:153-224; `atoms` selects the asymmetric proposal :197-215).
     Returns (x_new, key, lp_new, num_accepts) like the reference."""
-    del i, latvec                                  # the lattice lives in f.system
+    del i
     if atoms is not None:
-        raise NotImplementedError('asymmetric proposals (atoms != None): process.py never passes atoms and the '
-                                  'reference flags the branch untested (base_config.py:119-121)')
+        return _mh_update_asymmetric(params, f, x1, key, lp_1, num_accepts, latvec, stddev, atoms, normal, uniform)
     system = f.system
     normal, uniform = _noise(key, x1, lp_1, normal, uniform)
     x2 = system.mh_propose(x1, normal, stddev)                                   # :192-193

@@ -1,7 +1,7 @@
 """Oracle (test infrastructure): Metropolis walker update.
 
-Restates /root/reference/DeepSolid/qmc.py (symmetric all-electron branch, the
-only one process.py:183-189 reaches).  The JAX threefry stream cannot be
+Restates /root/reference/DeepSolid/qmc.py (all-electron moves: the symmetric branch
+process.py:183-189 reaches and the asymmetric `atoms=` proposal).  The JAX threefry stream cannot be
 reproduced, so the Gaussian proposal noise and the uniform acceptance numbers
 are explicit arguments; everything else follows the reference line by line.
 """
@@ -11,15 +11,43 @@ from . import distance
 from .network import _t
 
 
-# qmc.py:153-224 (atoms=None branch :191-196, accept/select :217-222)
+# qmc.py:26-42
+def _log_prob_gaussian(x, mu, sigma):
+    numer = torch.sum(-0.5 * ((x - mu) ** 2) / (sigma ** 2), dim=(1, 2, 3))
+    denom = x.shape[-1] * torch.sum(torch.log(sigma), dim=(1, 2, 3))
+    return numer - denom
+
+
+# qmc.py:45-60: harmonic mean of the (non-periodic) electron-nucleus distances
+def _harmonic_mean(x, atoms):
+    ae = x - atoms[None, ...]
+    r_ae = torch.linalg.norm(ae, dim=-1, keepdim=True)
+    return 1.0 / torch.mean(1.0 / r_ae, dim=-2, keepdim=True)
+
+
+# qmc.py:153-224 (atoms=None branch :191-196, asymmetric branch :197-215, accept/select :217-222)
 def mh_update(params, f, x1, lp_1, num_accepts, latvec, stddev=0.02, normal=None, uniform=None,
               atoms=None):
-    if atoms is not None:
-        raise NotImplementedError('asymmetric proposals are not restated (untested in the reference)')
-    x2 = x1 + stddev * normal                        # :192
-    x2, _ = distance.enforce_pbc(latvec, x2)         # :193
-    lp_2 = 2.0 * f(params, x2)                       # :195
-    ratio = lp_2 - lp_1                              # :196
+    if atoms is None:
+        x2 = x1 + stddev * normal                        # :192
+        x2, _ = distance.enforce_pbc(latvec, x2)         # :193
+        lp_2 = 2.0 * f(params, x2)                       # :195
+        ratio = lp_2 - lp_1                              # :196
+    else:
+        atoms = _t(atoms)
+        n = x1.shape[0]
+        x1 = x1.reshape(n, -1, 1, 3)                     # :199
+        hmean1 = _harmonic_mean(x1, atoms)               # :200
+        x2 = x1 + stddev * hmean1 * normal.reshape(x1.shape)   # :202
+        x2, _ = distance.enforce_pbc(latvec, x2.reshape(n, -1))   # :203-204
+        lp_2 = 2.0 * f(params, x2)                       # :205
+        x2 = x2.reshape(n, -1, 1, 3)
+        hmean2 = _harmonic_mean(x2, atoms)               # :208
+        lq_1 = _log_prob_gaussian(x1, x2, stddev * hmean1)   # :210
+        lq_2 = _log_prob_gaussian(x2, x1, stddev * hmean2)   # :211
+        ratio = lp_2 + lq_2 - lp_1 - lq_1                # :212
+        x1 = x1.reshape(n, -1)
+        x2 = x2.reshape(n, -1)
     rnd = torch.log(uniform)                         # :218
     cond = ratio > rnd                               # :219
     x_new = torch.where(cond[..., None], x2, x1)     # :220

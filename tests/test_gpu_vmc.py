@@ -45,8 +45,21 @@ def test_metropolis_vs_reference_vectors(name):
     assert frac.min() > -1e-9 and frac.max() < 1 + 1e-9
     with pytest.raises(ValueError):
         qmc.make_mcmc_step(slog.apply, 4, cell.a, importance_sampling=lambda *a: 0, one_electron_moves=True)
-    with pytest.raises(NotImplementedError):
-        qmc.mh_update(dp, slog.apply, cu(fx['mh_x1']), None, cu(fx['mh_lp1']), nacc, cell.a, atoms=cu(np.zeros((1, 3))))
+    if 'mha_x_new' in fx:      # asymmetric proposal (qmc.py:197-215) replaying the reference's noise
+        nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+        xa, _, lpa, nacc = qmc.mh_update(dp, slog.apply, cu(fx['mh_x1']), None, cu(fx['mh_lp1']), nacc, cell.a,
+                                         stddev=float(fx['mh_width']), atoms=cell.original_cell.atom_coords(),
+                                         normal=cu(fx['mha_normal']), uniform=cu(fx['mha_uniform']))
+        np.testing.assert_allclose(xa.cpu().numpy(), fx['mha_x_new'], atol=1e-10)
+        np.testing.assert_allclose(lpa.cpu().numpy(), fx['mha_lp_new'], atol=1e-8)
+        assert float(nacc.item()) == float(fx['mha_num_accepts'])
+        # ... and through make_mcmc_step with a generator
+        astep = qmc.make_mcmc_step(slog.apply, fx['mcmc_x0'].shape[0], cell.a, steps=3, atoms=cell.original_cell.atom_coords())
+        xs, pm = astep(dp, cu(fx['mcmc_x0']), 11, 0.05)
+        assert xs.shape == fx['mcmc_x0'].shape and 0.0 <= float(pm) <= 1.0
+    with pytest.raises(NotImplementedError):          # qmc.py:275
+        qmc.mh_one_electron_update(dp, slog.apply, cu(fx['mh_x1']), None, cu(fx['mh_lp1']), nacc, cell.a,
+                                   atoms=cu(np.zeros((1, 3))))
 
 
 @pytest.mark.parametrize('name', ['lih', 'bcc_li'])

@@ -98,6 +98,13 @@ def test_metropolis_matches_reference(name):
                      float(fx['mcmc_width']))
     np.testing.assert_allclose(xo.numpy(), fx['mcmc_x_out'], atol=1e-11)
     assert abs(float(pmove) - float(fx['mcmc_pmove'])) < 1e-15
+    if 'mha_x_new' in fx:      # asymmetric proposal (qmc.py:197-215), atoms = primitive-cell nuclei
+        xa, lpa, nacca = oqmc.mh_update(p, f, tt(fx['mh_x1']), tt(fx['mh_lp1']), 0.0, cell.a, stddev=float(fx['mh_width']),
+                                        normal=tt(fx['mha_normal']), uniform=tt(fx['mha_uniform']),
+                                        atoms=cell.original_cell.atom_coords())
+        np.testing.assert_allclose(xa.numpy(), fx['mha_x_new'], atol=1e-11)
+        np.testing.assert_allclose(lpa.numpy(), fx['mha_lp_new'], atol=1e-9)
+        assert float(nacca) == float(fx['mha_num_accepts'])
 
 
 @pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'bcc_li'])

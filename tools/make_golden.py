@@ -280,6 +280,11 @@ def main():
             xn, _, lpn, nacc = rqmc.mh_update(pnp, f_batch, wx, None, lp1, 0.0, sim.a, stddev=0.05)
             d.update(mh_x1=wx, mh_lp1=lp1, mh_normal=RECORDER.normals[0], mh_uniform=RECORDER.uniforms[0],
                      mh_width=0.05, mh_x_new=xn, mh_lp_new=lpn, mh_num_accepts=float(nacc))
+            # asymmetric proposal (atoms given: step width scaled by the harmonic mean of the nuclear distances, qmc.py:197-215)
+            RECORDER.reset(case['seed'] + 350)
+            xa, _, lpa, nacca = rqmc.mh_update(pnp, f_batch, wx, None, lp1, 0.0, sim.a, stddev=0.05, atoms=prim.atom_coords())
+            d.update(mha_normal=RECORDER.normals[0], mha_uniform=RECORDER.uniforms[0], mha_x_new=xa, mha_lp_new=lpa,
+                     mha_num_accepts=float(nacca))
             RECORDER.reset(case['seed'] + 400)
             step = rqmc.make_mcmc_step(f_batch, B, sim.a, steps=3)
             xs3, pmove = step(pnp, wx, None, 0.08)
