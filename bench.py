@@ -191,9 +191,9 @@ def main():
                      'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                      'traffic': None, 'traffic_detail': None, 'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch,
                      'flops_per_walker_layer': f_layer,
-                     # issue-rate ceiling of the instruction the kernel uses, measured on this part
-                     # (tools/gpu_probe.py; profiles/r01_mfma_f64_probe.json, r01_mfma44_probe.txt); `frac` uses `peak`
-                     'instruction_ceiling': {'v_mfma_f64_16x16x4_f64': 51.5, 'unit': 'TFLOP/s'} if dtype == torch.float64 else None},
+                     # measured issue rate of the MFMA the kernel uses (tools/gpu_probe.py, profiles/r01_mfma_f64_probe.json): the
+                     # datasheet rate is reachable with VGPR accumulators (51.5 TFLOP/s with AGPR accumulators); `frac` uses `peak`
+                     'instruction_rate': {'v_mfma_f64_16x16x4_f64': 77.7, 'unit': 'TFLOP/s'} if dtype == torch.float64 else None},
         'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},     # from one extra untimed step
     }
     if args.system == 'bcc_li' and dtype == torch.float64:

@@ -793,9 +793,11 @@ __global__ void k_calib_copy(const double* __restrict__ src, double* __restrict_
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-// fp64 MFMA issue-rate probe: NACC independent accumulators per wave
+// fp64 MFMA issue-rate probe: NACC independent accumulators per wave.  The (256, 2) launch bound makes the compiler keep
+// the accumulators in VGPRs: on gfx950 v_mfma_f64_16x16x4_f64 issues every 64 cycles with VGPR accumulators but only every
+// ~97 cycles when they live in AGPRs (tools/probes/mfma16_nacc.hip vs mfma44_probe.hip, profiles/r01_mfma44_probe.txt).
 template <int NACC>
-__global__ void __launch_bounds__(256) k_mfma_peak(long iters, double* out) {
+__global__ void __launch_bounds__(256, 2) k_mfma_peak(long iters, double* out) {
     typedef Acc4<double>::type acc_t;
     acc_t acc[NACC];
     for (int j = 0; j < NACC; ++j) acc[j] = acc_t{0, 0, 0, 0};
