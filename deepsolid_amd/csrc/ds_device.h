@@ -31,6 +31,29 @@ template <typename T> __device__ __forceinline__ int acc_row(int lane, int reg);
 template <> __device__ __forceinline__ int acc_row<double>(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 template <> __device__ __forceinline__ int acc_row<float>(int lane, int reg) { return 4 * (lane >> 4) + reg; }
 
+// ------------------------------------------------------------------ 16-lane row reductions / broadcasts on DPP
+// (the MFMA accumulator puts the 16 slots of a slot tile in the 16 lanes of a DPP row; DPP moves have a fraction of the
+// latency of the ds_bpermute behind __shfl)
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a row, result in every lane: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+template <typename T> __device__ __forceinline__ T row16_sum(T v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+// lane L of every row broadcast to its row (row_share:L)
+template <int L, typename T> __device__ __forceinline__ T row16_bcast(T v) { return dpp_mov<0x150 + L>(v); }
+
 // ------------------------------------------------------------------ math wrappers
 __device__ __forceinline__ double ds_tanh(double x) { return tanh(x); }
 __device__ __forceinline__ float ds_tanh(float x) { return tanhf(x); }

@@ -151,8 +151,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                     for (int s = 0; s < ST; ++s) { phi[s].re += Sr[16 * s]; phi[s].im += Si[16 * s]; }
                 }
                 if (oe.bias && valid && lr == 0) { phi[0].re += oe.bias[p]; phi[0].im += oe.bias[oe.nparam + p]; }
-                const Cx<T> f0(__shfl(phi[0].re, base), __shfl(phi[0].im, base));
-                const Cx<T> fL(__shfl(phi[0].re, base | 1), __shfl(phi[0].im, base | 1));
+                const Cx<T> f0(row16_bcast<0>(phi[0].re), row16_bcast<0>(phi[0].im));
+                const Cx<T> fL(row16_bcast<1>(phi[0].re), row16_bcast<1>(phi[0].im));
                 Cx<T> fo[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -231,8 +231,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 if (16 * s + lr >= 2) ss += z[s] * z[s];
             }
             if (lr == 0) z[0] += bn;
-            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
-            const T z0 = __shfl(z[0], base), zL = __shfl(z[0], base | 1);
+            ss = row16_sum(ss);
+            const T z0 = row16_bcast<0>(z[0]), zL = row16_bcast<1>(z[0]);
             const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
 #pragma unroll
             for (int s = 0; s < ST; ++s) {
