@@ -166,8 +166,9 @@ __global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __r
             const T v = hp[j];
             if (j < S.n_up) up += v; else dn += v;
         }
-        up += __shfl_xor(up, 1); up += __shfl_xor(up, 2); up += __shfl_xor(up, 4);
-        dn += __shfl_xor(dn, 1); dn += __shfl_xor(dn, 2); dn += __shfl_xor(dn, 4);
+        // 8-lane sums on DPP: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+        up += dpp_mov<0xB1>(up); up += dpp_mov<0x4E>(up); up += dpp_mov<0x141>(up);
+        dn += dpp_mov<0xB1>(dn); dn += dpp_mov<0x4E>(dn); dn += dpp_mov<0x141>(dn);
         if (part == 0) Ge[(size_t)k * PV + c] = up / T(S.n_up);
         if (part == 1 && S.nch > 1) Ge[(size_t)(K2 + k) * PV + c] = dn / T(S.n_dn);
     }
