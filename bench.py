@@ -7,7 +7,11 @@ batch of synthetic walkers already resident in HBM: kinetic energy (forward-Lapl
 that replaces the reference's pmean (train.py:78-80).  Walkers shard across ranks with no other
 communication ("scaling": "weak": every rank keeps `--batch` walkers).
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torchrun)
+    python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
+        N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or
+        -- when no launcher environment is present -- bench.py re-executes itself under that launcher.
+        weak (default): every rank keeps --batch walkers; strong: --batch is the global batch, split over the
+        ranks like process.py:72-77 (4096 global -> 512 per GPU at N = 8).
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the
 library over the timed region) and `cpu_baseline` (the oracle's reference-algorithm restatement,
@@ -62,39 +66,104 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
-def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0):
-    """Reference-algorithm CPU restatement (JAX unavailable): mode `for` of hamiltonian.py:45-70
-    (3N sequential iterations of two jvp-of-grad sweeps) + Ewald on the host cores.  Bounded sample:
-    the first `dirs` of the 3N loop iterations of one walker are timed and scaled by 3N/dirs (the
-    iterations are identical work); the accuracy check uses the oracle's forward-Laplacian mode."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walkers=64):
+    """Reference-algorithm CPU restatement (JAX is not installable here or on the GPU box; SURVEY 8(d) protocol).
+
+    `for` (the reference default, hamiltonian.py:45-70): `walkers` walkers batched with torch.func.vmap the way
+    train.py:64 vmaps the local energy, torch CPU float64 on all host cores.  Bounded sample: ONE of the 3N
+    fori_loop iterations (two jvp-of-grad sweeps; the iterations are identical work) is timed for the whole
+    vmapped batch, median of 3 after a warm-up, and scaled by 3N; the vmapped Ewald sum is timed in full.
+    `hessian` (hamiltonian.py:104-124, the faster schedule when memory allows) is timed on a 4-walker vmap as a
+    courtesy number.  Accuracy of the GPU energies: one walker against the autodiff `hessian` oracle (a different
+    algorithm from the HIP chain), three more against the forward-Laplacian oracle."""
+    from torch.func import vmap
     from oracle import forward_laplacian as ofl
     from oracle import hamiltonian as oham
     from oracle import network as onet
-    cores = min(os.cpu_count() or 1, 16)                  # small matrices: more threads only add sync cost
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     net = onet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
     p = onet.params_to_torch(params_np)
     ew = oham.local_ewald_energy(cell)
-    x0 = torch.as_tensor(x_np[0])
-    n3 = x0.shape[0]
-    oham.local_kinetic_energy_real_imag(net.apply, directions=1)(p, x0)      # warm-up
-    t0 = time.perf_counter(); oham.local_kinetic_energy_real_imag(net.apply, directions=2)(p, x0)
-    t_dir = (time.perf_counter() - t0) / 2
-    dirs = int(max(2, min(n3, seconds / max(t_dir, 1e-6))))
-    log(f'cpu baseline: {t_dir:.2f} s per loop iteration, timing {dirs} of {n3}')
-    t0 = time.perf_counter(); oham.local_kinetic_energy_real_imag(net.apply, directions=dirs)(p, x0)
-    t_ke = (time.perf_counter() - t0) * n3 / dirs
-    t0 = time.perf_counter(); e_ew = float(ew(x0)); t_ew = time.perf_counter() - t0
-    # accuracy of the GPU numbers on a few walkers (forward-Laplacian oracle, validated against `for`)
-    errs = []
-    for b in range(min(4, x_np.shape[0])):
+    nw = min(walkers, x_np.shape[0])
+    xs = torch.as_tensor(x_np[:nw])
+    n3 = xs.shape[1]
+    one_dir = vmap(lambda xx: oham.local_kinetic_energy_real_imag(net.apply, directions=1)(p, xx)[0])
+    t0 = time.perf_counter(); one_dir(xs[:2]); t_probe = time.perf_counter() - t0       # warm-up, and a cost probe
+    if t_probe * nw / 2 * 3 > 2 * seconds:                # keep the whole sample near `seconds`
+        nw = max(2, int(nw * seconds / (t_probe * nw / 2 * 3)))
+        xs = xs[:nw]
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); one_dir(xs); ts.append(time.perf_counter() - t0)
+    t_dir = float(np.median(ts))
+    t0 = time.perf_counter(); [ew(xx) for xx in xs]; t_ew = time.perf_counter() - t0
+    t_for = t_dir * n3 + t_ew
+    log(f'cpu baseline `for`: {t_dir:.2f} s per fori_loop iteration on {nw} vmapped walkers x {n3} iterations '
+        f'-> {t_for / nw:.2f} s per evaluation')
+    nh = min(4, nw)
+    kh = vmap(lambda xx: sum(oham.local_kinetic_energy_real_imag_hessian(net.apply)(p, xx)))
+    t0 = time.perf_counter(); ke_h = kh(xs[:nh]); t_h = time.perf_counter() - t0 + t_ew * nh / nw
+    log(f'cpu baseline `hessian`: {t_h / nh:.2f} s per evaluation ({nh} vmapped walkers)')
+    errs = [abs(complex(e_gpu[0]) - (complex(ke_h[0]) + float(ew(xs[0]))))]            # autodiff oracle
+    for b in range(1, min(4, x_np.shape[0])):
         xb = torch.as_tensor(x_np[b])
-        ref = complex(ofl.stages(p, xb, klist, cell, net_kw)['ke']) + float(ew(xb))
-        errs.append(abs(complex(e_gpu[b]) - ref))
-    return dict(value=1.0 / (t_ke + t_ew), unit='local-energy evals/s', cores=cores, kind='port',
-                sample=f'{dirs} of the {n3} fori_loop iterations of one walker (hamiltonian.py:59-66, scaled by '
-                       f'{n3}/{dirs}) + its Ewald sum; torch CPU float64, {cores} threads; '
-                       f'{t_ke + t_ew:.1f} s per evaluation'), max(errs)
+        errs.append(abs(complex(e_gpu[b]) - (complex(ofl.stages(p, xb, klist, cell, net_kw)['ke']) + float(ew(xb)))))
+    return dict(value=nw / t_for, unit='local-energy evals/s', cores=cores, kind='port', cpu=cpu_model(),
+                mode='for', hessian_mode_value=nh / t_h,
+                sample=f'{nw} walkers under torch.func.vmap; 1 of the {n3} fori_loop iterations (hamiltonian.py:59-66) timed, '
+                       f'median of 3, scaled by {n3}, + the Ewald sums in full; torch CPU float64, {cores} threads; '
+                       f'{t_for / nw:.2f} s per evaluation (`hessian` mode on {nh} vmapped walkers: {t_h / nh:.2f} s); '
+                       'reference-algorithm CPU restatement (no JAX available)'), max(errs)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU
+    (process.py:72-77,96 splits one batch over the local devices inside one process; here it is one process per GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world, global_batch, use_dist):
+    """The launcher + reduction path without a GPU (tests/test_host_cpu.py): every rank joins the process group,
+    the max-over-ranks time and the ranks_seen count go through the same all-reduces as the real run."""
+    import torch.distributed as dist
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+    dt = 1e-3 * (1 + rank)
+    ranks_seen = 1
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        seen = torch.zeros(world, dtype=torch.float64)
+        seen[rank] = 1.0
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.sum().item())
+    if rank == 0:
+        print(json.dumps({'metric': 'local-energy evals/sec', 'value': None, 'n_gpus': world, 'ranks_seen': ranks_seen,
+                          'scaling': args.scaling, 'dry_run': True, 'max_rank_seconds': dt,
+                          'config': {'batch_per_gpu': args.batch, 'global_batch': global_batch}}))
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def main():
@@ -109,21 +178,34 @@ def main():
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="process-group backend ('nccl' is RCCL on ROCm; 'gloo' only for the launcher test on CPU hosts)")
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / reduction plumbing only (no GPU work): every rank reports in, rank 0 prints the JSON line')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.scaling == 'strong':
-        args.batch = max(1, args.batch // world)
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started {world} ranks')
+    global_batch = args.batch if args.scaling == 'strong' else world * args.batch
+    if args.scaling == 'strong':                           # process.py:72-77: one global batch split over the devices
+        if args.batch % world:
+            raise SystemExit(f'--scaling strong: batch {args.batch} is not divisible by {world} ranks (process.py:75)')
+        args.batch = args.batch // world
     local = int(os.environ.get('LOCAL_RANK', 0))
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
     import torch.distributed as dist
     use_dist = world > 1 or 'RANK' in os.environ          # launched by torchrun: one process per GPU over RCCL
+    if args.dry_run:
+        return dry_run(args, rank, world, global_batch, use_dist)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(args.backend, device_id=dev)
 
     from deepsolid_amd import network, systems, train
     dtype = torch.float64 if args.dtype == 'f64' else torch.float32
@@ -160,10 +242,15 @@ def main():
     prof_all = sysd.profile_read()
     sysd.profile(False)
     log(f'{args.steps} steps in {dt:.3f} s; kernels: ' + ', '.join(f'{k}={v[0]:.1f}ms' for k, v in prof_all.items()))
+    ranks_seen = 1
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        seen = torch.zeros(world, dtype=torch.float64, device=dev)
+        seen[rank] = 1.0
+        dist.all_reduce(seen)                               # every rank that ran the timed region reports in
+        ranks_seen = int(seen.sum().item())
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -185,7 +272,8 @@ def main():
         'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': f'{args.system} {n_e} e- ({cell.nelec[0]},{cell.nelec[1]}), total_energy primal '
                                f'(E_kin forward-Laplacian + Ewald), default detnet ((256,32),)*3, 8 dets',
-                   'batch_per_gpu': args.batch, 'global_batch': world * args.batch, 'parallelism': f'walker-dp{world}'},
+                   'batch_per_gpu': args.batch, 'global_batch': global_batch, 'parallelism': f'walker-dp{world}'},
+        'ranks_seen': ranks_seen,
         'energy_mean_ha': float(loss), 'energy_imag_ha': float(aux.imaginary), 'variance': float(aux.variance),
         'roofline': {'bound': 'mfma', 'kernel': 'k_jet_gemm<%s,4,5,2> (hidden one-electron layers: K=%d MFMA GEMM + fused tanh-jet epilogue)' % ('double' if dtype == torch.float64 else 'float', h1 + nch * h2),
                      'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
@@ -209,7 +297,6 @@ def main():
         cb, err = cpu_baseline(cell, klist, net_kw, params_np, x_np, aux.local_energy[:8].cpu().numpy(), args.cpu_seconds)
         out['cpu_baseline'] = cb
         out['max_abs_err_ha'] = float(err)
-        out['speedup_vs_cpu_baseline'] = out['value'] / cb['value']
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out))

@@ -19,19 +19,25 @@ def get_restore_path(restore_path=None):
     return restore_path if restore_path else None          # checkpoint.py:27-36
 
 
+_UNREADABLE = (OSError, EOFError, zipfile.BadZipFile, pickle.UnpicklingError, ValueError)
+
+
+def _readable(fname):
+    try:
+        with open(fname, 'rb') as f:
+            np.load(f, allow_pickle=True)
+        return True
+    except _UNREADABLE:
+        return False          # empty / truncated file (a run killed while writing)
+
+
 def find_last_checkpoint(ckpt_path=None):
-    """Most recent readable ``qmcjax_ckpt_*`` in a directory, or None (checkpoint.py:39-68)."""
-    if ckpt_path and os.path.exists(ckpt_path):
-        files = [f for f in os.listdir(ckpt_path) if 'qmcjax_ckpt_' in f]
-        for file in sorted(files, reverse=True):
-            fname = os.path.join(ckpt_path, file)
-            with open(fname, 'rb') as f:
-                try:
-                    np.load(f, allow_pickle=True)
-                    return fname
-                except (OSError, EOFError, zipfile.BadZipFile, pickle.UnpicklingError, ValueError):
-                    pass        # empty / truncated file: try the next one
-    return None
+    """Newest readable ``qmcjax_ckpt_*`` of a directory, or None; unreadable files are skipped so a run killed
+    while saving falls back to the previous checkpoint (the behaviour of checkpoint.py:39-68)."""
+    if not ckpt_path or not os.path.isdir(ckpt_path):
+        return None
+    names = sorted((n for n in os.listdir(ckpt_path) if 'qmcjax_ckpt_' in n), reverse=True)
+    return next((os.path.join(ckpt_path, n) for n in names if _readable(os.path.join(ckpt_path, n))), None)
 
 
 def create_save_path(save_path=None):
@@ -53,6 +59,8 @@ def _map(tree, fn):
 def _to_numpy(a):
     if a is None:
         return None
+    if isinstance(a, (int, float)):
+        return a
     if hasattr(a, 'detach'):
         a = a.detach().cpu().numpy()
     return np.asarray(a)
@@ -61,7 +69,7 @@ def _to_numpy(a):
 def save(save_path, t, data, params, opt_state, mcmc_width, add_device_axis=True):
     """checkpoint.py:94-124.  Tensors are converted to numpy; with ``add_device_axis`` every array gets the
     leading (1, ...) axis the reference expects from its pmap-replicated state."""
-    lead = (lambda a: None if a is None else _to_numpy(a)[None]) if add_device_axis else _to_numpy
+    lead = (lambda a: a if a is None or isinstance(a, (int, float)) else _to_numpy(a)[None]) if add_device_axis else _to_numpy
     ckpt_filename = os.path.join(save_path, f'qmcjax_ckpt_{t:06d}.npz')
     with open(ckpt_filename, 'wb') as f:
         np.savez(f, t=t, data=lead(data), params=_map(params, lead),
@@ -71,22 +79,28 @@ def save(save_path, t, data, params, opt_state, mcmc_width, add_device_axis=True
 
 
 def restore(restore_filename, batch_size=None, shape_check=True, n_devices=1):
-    """checkpoint.py:127-165: -> (t, data, params, opt_state, mcmc_width) exactly as stored (t + 1 iterations
-    completed).  ``n_devices`` plays the role of jax.local_device_count() in the shape check."""
-    with open(restore_filename, 'rb') as f:
-        ckpt_data = np.load(f, allow_pickle=True)
-        t = ckpt_data['t'].tolist() + 1
-        data = ckpt_data['data']
-        params = ckpt_data['params'].tolist()
-        opt_state = ckpt_data['opt_state'].tolist()
-        mcmc_width = ckpt_data['mcmc_width'].tolist()
-        if shape_check:
-            if data.shape[0] != n_devices:
-                raise ValueError('Incorrect number of devices found. Expected {}, found {}.'.format(data.shape[0], n_devices))
-            if batch_size and data.shape[0] * data.shape[1] != batch_size:
-                raise ValueError('Wrong batch size in loaded data. Expected {}, found {}.'.format(
-                    batch_size, data.shape[0] * data.shape[1]))
-    return t, data, params, opt_state, mcmc_width
+    """-> (t, data, params, opt_state, mcmc_width) from a file in the layout of checkpoint.py:92-120; `t` is the
+    number of completed iterations (stored index + 1, checkpoint.py:143).  The same two consistency checks as
+    checkpoint.py:151-163: the leading axis of `data` is the device count (``n_devices`` stands in for
+    jax.local_device_count()) and devices x per-device batch is the configured batch."""
+    with np.load(restore_filename, allow_pickle=True) as ck:
+        stored = {k: ck[k] for k in ('t', 'data', 'params', 'opt_state', 'mcmc_width')}
+    data = stored['data']
+    if shape_check:
+        ndev, per_dev = data.shape[0], data.shape[1]
+        if ndev != n_devices:
+            raise ValueError(f'Incorrect number of devices found. Expected {ndev}, found {n_devices}.')
+        if batch_size and ndev * per_dev != batch_size:
+            raise ValueError(f'Wrong batch size in loaded data. Expected {batch_size}, found {ndev * per_dev}.')
+    unbox = lambda a: a.tolist()          # 0-d object / scalar arrays back to the python objects that were saved
+    return int(stored['t']) + 1, data, unbox(stored['params']), unbox(stored['opt_state']), unbox(stored['mcmc_width'])
+
+
+def opt_state_to_single_device(opt_state):
+    """Adam state written by `save` (leaves with the leading device axis) -> replica 0; scalars unchanged."""
+    if opt_state is None:
+        return None
+    return _map(opt_state, lambda a: a if isinstance(a, (int, float)) else np.asarray(a)[0])
 
 
 def to_single_device(data, params, mcmc_width=None):

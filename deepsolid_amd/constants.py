@@ -16,6 +16,10 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def pmean_if_pmap(obj, axis_name=PMAP_AXIS_NAME):
     del axis_name
     if world_size() == 1:

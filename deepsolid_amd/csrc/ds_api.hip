@@ -13,6 +13,7 @@
 
 #include "../../include/deepsolid_hip.h"
 #include "ds_grad.h"
+#include "ds_mcmc.h"
 
 namespace {
 
@@ -70,6 +71,7 @@ struct ds_system {
     // optional two-way chunk pipelining (DS_STREAMS=2): bandwidth-bound kernels of one chunk overlap the MFMA-bound
     // kernels of the other; the side streams fork from / join the caller's stream with events
     int n_streams = 1;
+    bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
@@ -473,7 +475,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const int nt = (2 * n + 15) / 16;
         const bool sw8 = ybytes16 > 150 * 1024;
         const size_t ybytes = sw8 ? ybytes8 : ybytes16;
-        if ((2 * n) % 4 == 0 && ybytes <= 150 * 1024 && nt <= 6 && !getenv("DS_DET_VALU")) {
+        if ((2 * n) % 4 == 0 && ybytes <= 150 * 1024 && nt <= 6 && !s->det_valu) {
 #define DS_TRM(NTV, SWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV>), dim3(S.K, (unsigned)Bc), dim3(256), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp])
@@ -673,7 +675,9 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
     if (s->n_streams == 2 && chunk >= 2 && B > chunk / 2 && !s->prof_on) {
         // two half-size workspaces, chunks alternate between two side streams
         const int64_t half = chunk / 2;
-        char* wsp[2] = {(char*)ws, (char*)ws + (size_t)half * s->ws.per_walker * sizeof(T)};
+        const size_t half_bytes = ((size_t)half * s->ws.per_walker * sizeof(T) + 255) / 256 * 256;
+        if (half_bytes + (size_t)half * s->ws.per_walker * sizeof(T) > (size_t)ws_bytes) return fail("workspace too small for DS_STREAMS=2");
+        char* wsp[2] = {(char*)ws, (char*)ws + half_bytes};
         HIP_OK(hipEventRecord(s->ev_fork, st));
         for (int k = 0; k < 2; ++k) HIP_OK(hipStreamWaitEvent(s->side[k], s->ev_fork, 0));
         int k = 0;
@@ -976,6 +980,42 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
     return 0;
 }
 
+
+// ------------------------------------------------------------------ Metropolis loop (qmc.py:335-362), ds_mcmc.h
+inline size_t mcmc_scratch_bytes(const ds_system* s, int64_t B) {
+    const size_t esz = s->dtype == 0 ? 8 : 4;
+    return (((size_t)B * 3 * s->sd.N + (size_t)B) * esz + 255) / 256 * 256;      // proposal x2 (B,3N) + log|psi(x2)| (B,)
+}
+
+template <typename T>
+int mcmc_step_impl(ds_system* s, const void* params, void* x_, void* lp_, int64_t B, int steps, double width, uint64_t seed,
+                   uint64_t offset, const void* normals_, const void* uniforms_, int lp_valid, void* n_accept, void* ws,
+                   int64_t ws_bytes, hipStream_t st) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const size_t head = mcmc_scratch_bytes(s, B);
+    if ((int64_t)head >= ws_bytes) return fail("workspace too small for ds_mcmc_step (see ds_mcmc_workspace_bytes)");
+    T* x = (T*)x_; T* lp = (T*)lp_;
+    T* X2 = (T*)ws; T* LA2 = X2 + (size_t)B * 3 * S.N;
+    void* wsv = (char*)ws + head;
+    const int64_t wsv_bytes = ws_bytes - (int64_t)head;
+    const T* normals = (const T*)normals_; const T* uniforms = (const T*)uniforms_;
+    const size_t ne = (size_t)B * S.N;
+    const ds::PhiloxKey key{seed, offset};
+    if (!lp_valid) {                                                     // logprob = 2 f(data)   qmc.py:357
+        if (int rc = logpsi_impl<T>(s, params, x, B, LA2, nullptr, wsv, wsv_bytes, st)) return rc;
+        hipLaunchKernelGGL((ds::k_scale2<T>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, LA2, (long)B, lp);
+    }
+    for (int i = 0; i < steps; ++i) {                                    // lax.fori_loop(0, nsteps, ...)   :358
+        hipLaunchKernelGGL((ds::k_mcmc_propose<T>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, S.sim_a, S.sim_ainv, x,
+                           normals ? normals + (size_t)i * B * 3 * S.N : (const T*)nullptr, key, (unsigned long long)i, (T)width, ne, X2);
+        if (int rc = logpsi_impl<T>(s, params, X2, B, LA2, nullptr, wsv, wsv_bytes, st)) return rc;
+        hipLaunchKernelGGL((ds::k_mcmc_accept<T>), dim3((unsigned)B), dim3(64), 0, st, x, lp, X2, LA2,
+                           uniforms ? uniforms + (size_t)i * B : (const T*)nullptr, key, (unsigned long long)i, 3 * S.N, 0L, (T*)n_accept);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int check_arch(const ds_system_desc* d) {
     if (d->dtype != 0 && d->dtype != 1) return fail("dtype must be 0 (f64) or 1 (f32)");
     if (d->distance_type != 0 && d->distance_type != 1) return fail("Unrecognized distance function.");
@@ -1015,18 +1055,26 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
         delete s;
         return fail("hipMalloc of the system tables failed (is a GPU visible?)");
     }
-    hipMemcpy(s->blob64, h64.data(), h64.size() * sizeof(double), hipMemcpyHostToDevice);
-    hipMemcpy(s->blob32, h32.data(), h32.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (hipMemcpy(s->blob64, h64.data(), h64.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(s->blob32, h32.data(), h32.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        ds_system_destroy(s);
+        return fail("upload of the system tables failed");
+    }
     relocate<double>(s->sd, (const double*)s->blob64);
     relocate<float>(s->sf, (const float*)s->blob32);
     build_layouts(s);
+    // environment switches are read here, once; the launch paths never call getenv
     if (const char* e = getenv("DS_STREAMS")) s->n_streams = atoi(e) == 2 ? 2 : 1;
+    s->det_valu = getenv("DS_DET_VALU") != nullptr;
     if (s->n_streams == 2) {
-        for (int k = 0; k < 2; ++k) {
-            (void)hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking);
-            (void)hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming);
+        bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            ds_system_destroy(s);
+            return fail("DS_STREAMS=2: creating the side streams / events failed");
         }
-        (void)hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
     }
     *out = s;
     return 0;
@@ -1184,6 +1232,44 @@ int ds_mh_accept(ds_system* s, void* x1, void* lp1, const void* x2, const void* 
                            (const float*)lp2, (const float*)uniform, 3 * s->sf.N, (float*)n_accept);
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+int64_t ds_mcmc_workspace_bytes(const ds_system* s, int64_t B) {
+    if (!s) return -1;
+    return ds_workspace_bytes(s, B) + (int64_t)mcmc_scratch_bytes(s, std::max<int64_t>(B, 1));
+}
+
+int ds_mcmc_step(ds_system* s, const void* params, void* x, void* lp, int64_t B, int steps, double width, uint64_t philox_seed,
+                 uint64_t philox_offset, const void* normals, const void* uniforms, int lp_valid, void* n_accept, void* ws,
+                 int64_t ws_bytes, void* stream) {
+    if (!s || !params || !x || !lp || !n_accept || !ws) return fail("null argument");
+    if ((normals == nullptr) != (uniforms == nullptr)) return fail("normals and uniforms must be given together (or both NULL)");
+    if (steps < 0) return fail("steps must be >= 0");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return s->dtype == 0 ? mcmc_step_impl<double>(s, params, x, lp, B, steps, width, philox_seed, philox_offset, normals, uniforms,
+                                                  lp_valid, n_accept, ws, ws_bytes, st)
+                         : mcmc_step_impl<float>(s, params, x, lp, B, steps, width, philox_seed, philox_offset, normals, uniforms,
+                                                 lp_valid, n_accept, ws, ws_bytes, st);
+}
+
+int ds_energy_stats(ds_system* s, const void* ke, const void* ewald, int64_t B, double* out_stats, void* stream) {
+    if (!s || !ke || !ewald || !out_stats) return fail("null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (s->dtype == 0)
+        hipLaunchKernelGGL((ds::k_energy_stats<double>), dim3(1), dim3(256), 0, st, (const double*)ke, (const double*)ewald, (long)B, out_stats);
+    else
+        hipLaunchKernelGGL((ds::k_energy_stats<float>), dim3(1), dim3(256), 0, st, (const float*)ke, (const float*)ewald, (long)B, out_stats);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+void ds_philox_host(uint64_t seed, uint64_t offset, uint64_t step, uint64_t index, int stream_id, uint32_t out[4]) {
+    const uint64_t off = offset + step;
+    const ds::Philox4 r = ds::philox4x32_10((unsigned)index, (unsigned)(index >> 32), (unsigned)off,
+                                            ((unsigned)(off >> 32) & 0x3fffffffu) | ((unsigned)stream_id << 30), (unsigned)seed,
+                                            (unsigned)(seed >> 32));
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
 }
 
 int ds_orbitals(ds_system* s, const void* params, const void* x, int64_t B, void* out_up, void* out_dn, void* ws, int64_t ws_bytes,

@@ -104,6 +104,7 @@ class DeviceSystem:
         self._ws = None
         self._packed = None
         self._packed_key = None
+        self._packed_leaves = []
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -179,8 +180,12 @@ class DeviceSystem:
             else:
                 leaves.append(o)
         walk(params)
-        key = tuple((id(t), getattr(t, '_version', 0)) for t in leaves)
-        if self._packed is not None and key == self._packed_key:
+        # cache only trees of tensors: the key holds the leaves themselves (so ids cannot be recycled), their
+        # storage address and version counter; numpy leaves have no version counter and are packed every call
+        cacheable = all(isinstance(t, torch.Tensor) for t in leaves)
+        key = tuple((t.data_ptr(), t._version) for t in leaves) if cacheable else None
+        if cacheable and self._packed is not None and key == self._packed_key and \
+                len(leaves) == len(self._packed_leaves) and all(a is b for a, b in zip(leaves, self._packed_leaves)):
             return self._packed
 
         def dev(a):
@@ -252,7 +257,7 @@ class DeviceSystem:
             put(dev(params['envelope'][c]['pi']))
             # sigma: (A, P) isotropic | (A, 3, P) diagonal -> rows a*3+c | (3, 3, A, P) full -> rows (k*3+m)*A+a
             put(dev(params['envelope'][c]['sigma']).reshape(-1, nparam))
-        self._packed, self._packed_key = flat, key
+        self._packed, self._packed_key, self._packed_leaves = (flat, key, leaves) if cacheable else (None, None, [])
         return flat
 
     def _orbital_column_map(self, nparam, cols):
@@ -384,14 +389,14 @@ class DeviceSystem:
             counter[0] += n
             return out
         numbered = number(params)
-        saved = (self._packed, self._packed_key)
+        saved = (self._packed, self._packed_key, self._packed_leaves)
         try:
             self._pack_dtype = torch.float64    # entry numbers must survive the packing exactly
             self._packed = None
             flat = self.pack_params(numbered).round().to(torch.int64)
         finally:
             self._pack_dtype = None
-            self._packed, self._packed_key = saved
+            self._packed, self._packed_key, self._packed_leaves = saved
         total = counter[0] - 1
         pos = torch.full((total + 1,), -1, dtype=torch.int64, device=self.device)
         nz = torch.nonzero(flat > 0).reshape(-1)
@@ -447,6 +452,39 @@ class DeviceSystem:
         """In-place select on x1 / lp1; n_accept (1,) is incremented."""
         _lib.check(self.lib.ds_mh_accept(self.handle, _ptr(x1), _ptr(lp1), _ptr(x2), _ptr(lp2), _ptr(uniform),
                                          x1.shape[0], _ptr(n_accept), _stream()), 'ds_mh_accept')
+
+    def mcmc_step(self, params, x, lp, steps, width, seed=0, offset=0, normals=None, uniforms=None, lp_valid=False,
+                  n_accept=None):
+        """`ds_mcmc_step`: `steps` all-electron Metropolis moves on x (B,3N) / lp (B,) IN PLACE, enqueued without a host
+        synchronisation.  Noise from the in-kernel Philox stream (seed, offset) or replayed from `normals`
+        (steps,B,3N) / `uniforms` (steps,B).  -> n_accept (1,) device tensor (incremented)."""
+        x = self._check_x(x)
+        B = x.shape[0]
+        p = self.pack_params(params)
+        if n_accept is None:
+            n_accept = torch.zeros(1, dtype=self.dtype, device=self.device)
+        if B == 0 or steps == 0 and lp_valid:
+            return n_accept
+        if normals is not None:
+            normals = normals.to(device=self.device, dtype=self.dtype).contiguous()
+            uniforms = uniforms.to(device=self.device, dtype=self.dtype).contiguous()
+            if tuple(normals.shape) != (steps, B, 3 * self.n) or tuple(uniforms.shape) != (steps, B):
+                raise ValueError('explicit noise must be normals (steps, B, 3N) and uniforms (steps, B)')
+        need = int(self.lib.ds_mcmc_workspace_bytes(self.handle, int(B)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.ds_mcmc_step(self.handle, _ptr(p), _ptr(x), _ptr(lp), B, int(steps), float(width),
+                                         int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _ptr(normals), _ptr(uniforms),
+                                         int(bool(lp_valid)), _ptr(n_accept), _ptr(self._ws), self._ws.numel(), _stream()),
+                   'ds_mcmc_step')
+        return n_accept
+
+    def energy_stats(self, ke, ew):
+        """`ds_energy_stats`: (8,) float64 = [sum Re E_L, sum Im E_L, sum |E_L|^2, n, n_nonfinite, sum Re ke, sum Im ke, sum ew]."""
+        out = torch.empty(8, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.ds_energy_stats(self.handle, _ptr(ke), _ptr(ew), ke.shape[0], _ptr(out), _stream()), 'ds_energy_stats')
+        return out
 
     def profile(self, on=True, only=None):
         """Start (and reset) / stop per-kernel HIP-event timing inside the library; `only` = one

@@ -41,13 +41,24 @@ class Writer:
         self._file.close()
 
 
+def _rank_generator(key, device):
+    """Per-rank noise stream: the reference folds the host index into the key and splits it per device
+    (process.py:104, constants.py:54-57); here one process drives one GPU, so the rank is folded into the seed.
+    Walkers must be initialised per rank as well (`init_guess.init_electrons` takes its own key)."""
+    if isinstance(key, torch.Generator):
+        return key
+    from . import constants
+    seed = int(key) * max(1, constants.world_size()) + constants.rank()
+    return torch.Generator(device=device).manual_seed(seed)
+
+
 def run_inference(slog_net, logdet_net, params, data, simulation_cell, iterations, key=0, move_width=0.02,
                   mcmc_steps=20, burn_in=100, adapt_frequency=100, stats_frequency=1, save_path=None,
                   stats_file_name='train_stats', laplacian_mode='for', partition_number=3):
     """Returns (data, mcmc_width, rows).  `slog_net` / `logdet_net` are the objects returned by
     ``make_solid_fermi_net(method_name='eval_slogdet' | 'eval_logdet')``; `data` is (B, 3N) on the device.
     Energies are reported per primitive cell like process.py:330-334 (divided by ``simulation_cell.scale``)."""
-    gen = key if isinstance(key, torch.Generator) else torch.Generator(device=data.device).manual_seed(int(key))
+    gen = _rank_generator(key, data.device)
     batch = data.shape[0]
     mcmc_step = qmc.make_mcmc_step(slog_net.apply, batch, latvec=simulation_cell.a, steps=mcmc_steps)
     total_energy = train.make_loss(logdet_net.apply, None, simulation_cell, mode=laplacian_mode,
@@ -103,7 +114,7 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
     checkpoints in the reference's layout (`deepsolid_amd.checkpoint.save`) every `save_every` iterations.
     `params` is updated in place.  Returns (data, params, opt_state, mcmc_width, rows)."""
     from . import checkpoint
-    gen = key if isinstance(key, torch.Generator) else torch.Generator(device=data.device).manual_seed(int(key))
+    gen = _rank_generator(key, data.device)
     batch = data.shape[0]
     mcmc_step = qmc.make_mcmc_step(slog_net.apply, batch, latvec=simulation_cell.a, steps=mcmc_steps)
     total_energy = train.make_loss(logdet_net.apply, None, simulation_cell, clip_local_energy=clip_local_energy,
@@ -113,14 +124,16 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
         opt_state = opt_init(params)
     step = train.make_training_step(mcmc_step, total_energy, opt_update)
     width = float(move_width)
-    for _ in range(burn_in):
-        data, _ = mcmc_step(params, data, gen, width)
+    if t_init == 0:                                                      # process.py:256: burn-in only on a fresh start
+        for _ in range(burn_in):
+            data, _ = mcmc_step(params, data, gen, width)
     scale = float(getattr(simulation_cell, 'scale', 1))
     pmoves = np.zeros(adapt_frequency)
     rows = []
     writer = Writer(stats_file_name, TRAIN_SCHEMA, save_path) if save_path else None
     if writer:
         writer.__enter__()
+    t_last = t_init + iterations - 1
     try:
         for t in range(t_init, t_init + iterations):
             data, params, opt_state, loss, aux, pmove, _ = step(t, data, params, opt_state, gen, width)
@@ -137,8 +150,10 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
                     width /= 1.1
                 pmoves[:] = 0
             pmoves[t % adapt_frequency] = float(pmove)
-            if save_path and save_every and (t + 1) % save_every == 0:
-                checkpoint.save(save_path, t, data, params, None, width)
+            # process.py:376-383: every `save_every` iterations and always at the last one; the Adam moments and
+            # step count travel with the parameters (process.py:381 saves opt_state)
+            if save_path and ((save_every and (t + 1) % save_every == 0) or t >= t_last):
+                checkpoint.save(save_path, t, data, params, opt_state, width)
     finally:
         if writer:
             writer.__exit__(None, None, None)

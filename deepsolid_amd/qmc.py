@@ -4,9 +4,13 @@
 ``mcmc_step(params, data, key, width) -> (data, pmove)``.  The proposal + wrap
 (qmc.py:192-193) and the accept/select (qmc.py:217-222) are HIP kernels
 (``ds_mh_propose`` / ``ds_mh_accept``); the wavefunction call in between is the
-batched value-only log-psi kernel chain.  ``key`` is a ``torch.Generator`` on the
-device (or an int seed): torch's Philox stream replaces JAX's threefry; explicit
-noise ``(normals, uniforms)`` can be supplied instead for reproducible tests.
+batched value-only log-psi kernel chain.  The default sampler (all-electron,
+symmetric) runs as ONE C-ABI call, ``ds_mcmc_step``: all `steps` moves are enqueued
+without touching the host and the noise is a counter-based Philox4x32-10 stream
+evaluated inside the kernels (replacing JAX's threefry, qmc.py:190-192,217-218).
+``key`` is an int seed or a ``torch.Generator``; explicit noise ``(normals,
+uniforms)`` can be supplied instead for replay tests.  The other samplers draw
+from torch's generator and call the propose / accept kernels per move.
 
 All three samplers of the reference are available: all-electron Metropolis
 (``mh_update``, the default), one-electron moves (``mh_one_electron_update``) and
@@ -35,6 +39,16 @@ def _noise(key, x1, lp_1, normal, uniform, normal_shape=None):
     if uniform is None:
         uniform = torch.rand(lp_1.shape, dtype=lp_1.dtype, device=lp_1.device, generator=key)
     return normal, uniform
+
+
+def _check_latvec(latvec, system):
+    """The fused propose kernels wrap with the simulation cell the system was built for; a different `latvec`
+    (reference qmc.py:193 wraps with whatever it is given) must not be ignored silently."""
+    if latvec is None:
+        return
+    a = torch.as_tensor(latvec, dtype=torch.float64).cpu().reshape(3, 3)
+    if not torch.allclose(a, torch.as_tensor(system.cell.a, dtype=torch.float64).reshape(3, 3), rtol=1e-12, atol=1e-12):
+        raise ValueError('latvec differs from the lattice of the simulation cell the network was built for')
 
 
 def limdrift(g, cutoff=1):
@@ -89,6 +103,7 @@ def mh_update(params, f, x1, key, lp_1, num_accepts, latvec=None, stddev=0.02, a
     if atoms is not None:
         return _mh_update_asymmetric(params, f, x1, key, lp_1, num_accepts, latvec, stddev, atoms, normal, uniform)
     system = f.system
+    _check_latvec(latvec, system)
     normal, uniform = _noise(key, x1, lp_1, normal, uniform)
     x2 = system.mh_propose(x1, normal, stddev)                                   # :192-193
     lp_2 = 2.0 * f(params, x2)                                                   # :195
@@ -100,10 +115,10 @@ def mh_update(params, f, x1, key, lp_1, num_accepts, latvec=None, stddev=0.02, a
 def mh_one_electron_update(params, f, x1, key, lp_1, num_accepts, latvec=None, stddev=0.02, atoms=None, i=0,
                            normal=None, uniform=None):
     """Metropolis step that moves electron i % N only (qmc.py:227-287)."""
-    del latvec
     if atoms is not None:
         raise NotImplementedError('Still need to work out reverse probabilities for asymmetric moves.')   # qmc.py:275
     system = f.system
+    _check_latvec(latvec, system)
     nelec = x1.shape[1] // 3
     ii = i % nelec
     normal, uniform = _noise(key, x1, lp_1, normal, uniform, normal_shape=(x1.shape[0], 3))
@@ -128,7 +143,7 @@ def importance_update(params, f, x1, key, lp_1, num_accepts, latvec, stddev=0.02
     _, grad = f(params, x1)                                                       # :111
     grad = limdrift(grad)
     gauss = stddev * normal
-    x2, _ = distance.enforce_pbc(latvec, x1 + gauss + stddev ** 2 * grad)         # :114-115
+    x2, _ = distance.enforce_pbc(latvec if latvec is not None else system.cell.a, x1 + gauss + stddev ** 2 * grad)   # :114-115
     lpsi_2, new_grad = f(params, x2)                                              # :118
     new_grad = limdrift(new_grad)
     forward = (gauss ** 2).sum(-1)
@@ -153,8 +168,37 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
         func = batch_slog_network
         inner_fun = mh_one_electron_update if one_electron_moves else mh_update                  # qmc.py:327-333
 
+    fused = importance_sampling is None and not one_electron_moves and atoms is None
+    system = batch_slog_network.system
+    if fused:
+        _check_latvec(latvec, system)
+    gen_calls = {}                            # stateful torch.Generator keys: Philox offset advanced by `steps` per call
+
+    def fused_step(params, data, key, width):
+        """The default sampler as ONE C-ABI call (`ds_mcmc_step`): proposal, wrap, log|psi|, accept/select for all
+        `steps` moves are enqueued back to back; the noise is Philox evaluated inside the kernels.  `key`: an int is a
+        pure key like a JAX PRNGKey (same key -> same moves; the caller passes a fresh one per iteration, the rank is
+        folded in); a torch.Generator is stateful (its initial_seed keys the stream and every call advances the
+        offset by `steps`); a tuple (normals, uniforms) replays explicit noise."""
+        data = data.clone()
+        lp = torch.empty(data.shape[0], dtype=data.dtype, device=data.device)
+        if isinstance(key, (tuple, list)):
+            nacc = system.mcmc_step(params, data, lp, steps, width, normals=key[0], uniforms=key[1])
+        else:
+            if isinstance(key, torch.Generator):
+                seed = key.initial_seed()
+                _, off = gen_calls.get(id(key), (key, 0))
+                gen_calls[id(key)] = (key, off + steps)           # (holding the generator keeps its id unique)
+            else:
+                seed, off = int(key) * max(1, constants.world_size()) + constants.rank(), 0
+            nacc = system.mcmc_step(params, data, lp, steps, width, seed=seed, offset=off)
+        pmove = nacc[0] / (steps * batch_per_device)                              # qmc.py:360
+        return data, constants.pmean_if_pmap(pmove)                              # :361
+
     def mcmc_step(params, data, key, width):
         """noise: `key` = torch.Generator / int seed, or a tuple (normals (nsteps,B,...), uniforms (nsteps,B))."""
+        if fused and steps > 0:
+            return fused_step(params, data, key, width)
         explicit = isinstance(key, (tuple, list))
         gen = None if explicit else _generator(key, data.device)
         nelec = data.shape[-1] // 3

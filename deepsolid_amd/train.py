@@ -17,7 +17,9 @@ import torch
 
 from . import constants, hamiltonian
 
-AuxiliaryLossData = namedtuple('AuxiliaryLossData', ['variance', 'local_energy', 'imaginary', 'kinetic', 'ewald'])
+# the reference's five fields (train.py:28-34) + the non-finite count behind its check_nan step rejection (process.py:303-318)
+AuxiliaryLossData = namedtuple('AuxiliaryLossData', ['variance', 'local_energy', 'imaginary', 'kinetic', 'ewald', 'n_nonfinite'],
+                               defaults=[None])
 
 
 def clip_difference(diff, clip_local_energy, clip_type):
@@ -54,10 +56,14 @@ def make_loss(network, batch_network, simulation_cell, clip_local_energy=5.0, cl
     def total_energy(params, data):
         ke, ew = el_fun(params, data)                                  # train.py:74
         e_l = ke + ew                                                  # :75
-        mean_e_l = e_l.mean()                                          # :76
-        var_local = (e_l.abs() ** 2).mean() - mean_e_l.real.abs() ** 2  # :79 (per-device variance, then pmean)
-        re, im, var = constants.pmean_packed(mean_e_l.real, mean_e_l.imag, var_local)   # :78-80 in one message
-        return re, AuxiliaryLossData(variance=var, local_energy=e_l, imaginary=im, kinetic=ke, ewald=ew)
+        # one deterministic device reduction (ds_energy_stats) -> [sum Re, sum Im, sum |E|^2, n, n_nonfinite, ...]
+        st = system.energy_stats(torch.view_as_real(ke), ew)
+        n = st[3].clamp(min=1.0)
+        mean_re, mean_im = st[0] / n, st[1] / n                        # :76
+        var_local = st[2] / n - mean_re.abs() ** 2                     # :79 (per-device variance, then pmean)
+        # :78-80 (+ the non-finite count, summed not averaged) in ONE all-reduce of a packed vector
+        re, im, var, bad = constants.pmean_packed(mean_re, mean_im, var_local, st[4] * constants.world_size())
+        return re, AuxiliaryLossData(variance=var, local_energy=e_l, imaginary=im, kinetic=ke, ewald=ew, n_nonfinite=bad)
 
     def value_and_grad_packed(params, data):
         """-> ((loss, aux), packed gradient of this rank's walkers)."""
@@ -94,12 +100,16 @@ def adam(learning_rate=1e-3, b1=0.9, b2=0.999, eps=1e-8):
 
     def init(params):
         ps = leaves(params, [])
-        return {'m': [torch.zeros_like(p) for p in ps], 'v': [torch.zeros_like(p) for p in ps]}
+        return {'count': 0, 'm': [torch.zeros_like(p) for p in ps], 'v': [torch.zeros_like(p) for p in ps]}
 
     def update(t, grads, params, state):
         lr = learning_rate(t) if callable(learning_rate) else learning_rate
         ps, gs = leaves(params, []), leaves(grads, [])
-        step = int(t) + 1
+        # the bias correction follows the optimiser's own step count (optax keeps `count` in its state), not the
+        # driver's iteration index: a restored state continues where it stopped
+        state['count'] = step = int(state.get('count', int(t))) + 1
+        state['m'] = [torch.as_tensor(m, dtype=p.dtype, device=p.device) for m, p in zip(state['m'], ps)]
+        state['v'] = [torch.as_tensor(v, dtype=p.dtype, device=p.device) for v, p in zip(state['v'], ps)]
         for p, g, m, v in zip(ps, gs, state['m'], state['v']):
             m.mul_(b1).add_(g, alpha=1 - b1)
             v.mul_(b2).addcmul_(g, g, value=1 - b2)

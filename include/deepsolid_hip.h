@@ -173,6 +173,33 @@ int ds_mh_propose(ds_system* sys, const void* x1, const void* normal, double wid
 int ds_mh_accept(ds_system* sys, void* x1, void* lp1, const void* x2, const void* lp2,
                  const void* uniform, int64_t B, void* n_accept, void* stream);
 
+/* qmc.make_mcmc_step's jitted loop (qmc.py:335-362) for the default sampler (all-electron symmetric mh_update,
+ * qmc.py:153-196,217-222): `steps` moves enqueued back to back on `stream`, no host synchronisation:
+ *     [lp = 2 log|psi(x)|  if !lp_valid (:357)]
+ *     repeat steps times:  x2 = wrap(x + width * N(0,1));  lp2 = 2 log|psi(x2)|;
+ *                          accept iff lp2 - lp > log u;  x, lp <- select;  n_accept[0] += #accepted
+ * Noise: a counter-based Philox4x32-10 generator evaluated inside the kernels replaces jax.random.split / normal /
+ * uniform (:190-192, :217-218): the draw for (move i, electron e | walker w) is a pure function of
+ * (philox_seed, philox_offset + i, index), so runs are reproducible and ranks decorrelate by seed.  A caller
+ * advances philox_offset by `steps` between calls.  Test mode: `normals` (steps, B, 3N) and `uniforms` (steps, B)
+ * device arrays replay caller-supplied noise instead (both or neither).
+ * x (B,3N) and lp (B,) are updated in place; n_accept (1,) of dtype is incremented (pmove = n_accept / (steps * B),
+ * qmc.py:360).  Workspace: ds_mcmc_workspace_bytes(sys, B). */
+int64_t ds_mcmc_workspace_bytes(const ds_system* sys, int64_t B);
+int ds_mcmc_step(ds_system* sys, const void* params, void* x, void* lp, int64_t B, int steps, double width,
+                 uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms,
+                 int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream);
+/* the raw Philox block ds_mcmc_step uses for (seed, offset + step, index, stream_id): host evaluation for tests
+ * (stream_id 0 / 1: normal deviates of electron `index`, 2: the uniform deviate of walker `index`). */
+void ds_philox_host(uint64_t seed, uint64_t offset, uint64_t step, uint64_t index, int stream_id, uint32_t out[4]);
+
+/* Packed batch statistics of train.make_loss.total_energy (train.py:74-82) in one deterministic reduction:
+ * out_stats (8,) float64 on the device =
+ *   [ sum Re E_L, sum Im E_L, sum |E_L|^2, n, n_nonfinite, sum Re E_kin, sum Im E_kin, sum E_ewald ],  E_L = ke + ewald.
+ * The vector is what crosses GPUs in ONE all-reduce (replacing the pmeans of train.py:78-80); n_nonfinite is the
+ * count behind the reference's optional check_nan step rejection (process.py:303-318). */
+int ds_energy_stats(ds_system* sys, const void* ke, const void* ewald, int64_t B, double* out_stats, void* stream);
+
 /* Stage dumps for parity tests (tests only; sizes documented in DESIGN.md).
  * Runs the forward-Laplacian chain for the first walkers of the batch and copies
  * the named intermediate into `out` (device, dtype elements).  Returns elements written. */

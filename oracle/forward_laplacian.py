@@ -53,8 +53,8 @@ def _tanh_jet(z):
 def stages(params, x, klist, simulation_cell, net_kw):
     """Forward-Laplacian through the network for ONE walker.  Returns a dict of
     every intermediate jet tensor (used for stage-by-stage HIP debugging)."""
-    if net_kw.get('full_det', False) or net_kw.get('envelope_type', 'isotropic') != 'isotropic':
-        raise NotImplementedError('forward-Laplacian oracle covers the tested default: isotropic, block-diagonal dets')
+    if net_kw.get('full_det', False) or net_kw.get('envelope_type', 'isotropic') != 'isotropic' or net_kw.get('bias_orbitals', False):
+        raise NotImplementedError('forward-Laplacian oracle covers the tested default: isotropic, block-diagonal dets, no orbital bias')
     dist = {'nu': onet.nu_distance, 'tri': onet.tri_distance}[net_kw.get('distance_type', 'nu')]
     prim = simulation_cell.original_cell
     spins = tuple(int(s) for s in simulation_cell.nelec)

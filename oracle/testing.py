@@ -83,23 +83,38 @@ def klist_from_kpts(kpts, nelec):
 
 
 # name -> recipe.  `system` keys deepsolid_amd.systems.SYSTEMS.
+#   ke_walkers   : walkers whose kinetic energy comes from the reference's own hamiltonian.py (modes in ke_modes)
+#   grad_walkers : batch for the reference's own train.make_loss + jax.value_and_grad (clip types in grad_clip_types)
+#   fd_walkers / gradfd_walkers : finite differences of the reference-executed forward (side checks)
+_ALL_MODES = ('for', 'hessian', 'dim_batch', 'partition')
 CASES = {
-    'h2':            dict(system='h2', seed=11, batch=4, fd_walkers=2),
-    'lih':           dict(system='lih', seed=12, batch=6, fd_walkers=3, gradfd_walkers=3),
-    'lih_twist':     dict(system='lih', seed=13, batch=4, twist=(0.25, 0.1, 0.4), fd_walkers=2, gradfd_walkers=2),
-    'lih_2x1x1':     dict(system='lih', seed=14, batch=3, system_kw=dict(S=np.diag([2, 1, 1])), mcmc=False),
-    'bcc_li':        dict(system='bcc_li', seed=15, batch=4, fd_walkers=1, fd_h=5e-4, fd_tol=1e-5, gradfd_walkers=2),
-    'bcc_li_twist':  dict(system='bcc_li', seed=16, batch=2, twist=(0.3, 0.0, 0.15), mcmc=False),
-    'graphene':      dict(system='graphene', seed=17, batch=2, mcmc=False),
-    'diamond':       dict(system='diamond', seed=18, batch=2, mcmc=False),
-    'lih_fulldet':   dict(system='lih', seed=19, batch=3, net_kw=dict(full_det=True), mcmc=False, gradfd_walkers=2),
-    'lih_tri':       dict(system='lih', seed=20, batch=3, net_kw=dict(distance_type='tri'), mcmc=False, gradfd_walkers=2),
-    'lih_diagenv':   dict(system='lih', seed=21, batch=3, net_kw=dict(envelope_type='diagonal'), mcmc=False),
-    'lih_fullenv':   dict(system='lih', seed=22, batch=3, net_kw=dict(envelope_type='full'), mcmc=False),
-    'lih_lastlayer': dict(system='lih', seed=26, batch=3, net_kw=dict(use_last_layer=True), mcmc=False),
-    'lih_bias':      dict(system='lih', seed=23, batch=3, net_kw=dict(bias_orbitals=True), mcmc=False),
+    'h2':            dict(system='h2', seed=11, batch=4, fd_walkers=2, ke_walkers=4, ke_modes=_ALL_MODES, grad_walkers=4),
+    'lih':           dict(system='lih', seed=12, batch=6, fd_walkers=3, gradfd_walkers=3, ke_walkers=6,
+                          ke_modes=_ALL_MODES, grad_walkers=6, grad_clip_types=('real', 'complex')),
+    'lih_twist':     dict(system='lih', seed=13, batch=4, twist=(0.25, 0.1, 0.4), fd_walkers=2, gradfd_walkers=2,
+                          ke_walkers=4, ke_modes=_ALL_MODES, grad_walkers=4, grad_clip_types=('real', 'complex')),
+    'lih_2x1x1':     dict(system='lih', seed=14, batch=3, system_kw=dict(S=np.diag([2, 1, 1])), mcmc=False,
+                          ke_walkers=3, grad_walkers=3),
+    'bcc_li':        dict(system='bcc_li', seed=15, batch=4, fd_walkers=1, fd_h=5e-4, fd_tol=1e-5, gradfd_walkers=2,
+                          ke_walkers=4, ke_modes=('for', 'hessian'), grad_walkers=4),
+    'bcc_li_twist':  dict(system='bcc_li', seed=16, batch=2, twist=(0.3, 0.0, 0.15), mcmc=False, ke_walkers=2),
+    'graphene':      dict(system='graphene', seed=17, batch=2, mcmc=False, ke_walkers=2, ke_modes=('for', 'hessian')),
+    'diamond':       dict(system='diamond', seed=18, batch=2, mcmc=False, ke_walkers=2),
+    'lih_fulldet':   dict(system='lih', seed=19, batch=3, net_kw=dict(full_det=True), mcmc=False, gradfd_walkers=2,
+                          ke_walkers=3, grad_walkers=3),
+    'lih_tri':       dict(system='lih', seed=20, batch=3, net_kw=dict(distance_type='tri'), mcmc=False, gradfd_walkers=2,
+                          ke_walkers=3, grad_walkers=3),
+    'lih_diagenv':   dict(system='lih', seed=21, batch=3, net_kw=dict(envelope_type='diagonal'), mcmc=False,
+                          ke_walkers=3, grad_walkers=3),
+    'lih_fullenv':   dict(system='lih', seed=22, batch=3, net_kw=dict(envelope_type='full'), mcmc=False,
+                          ke_walkers=3, grad_walkers=3),
+    'lih_lastlayer': dict(system='lih', seed=26, batch=3, net_kw=dict(use_last_layer=True), mcmc=False,
+                          ke_walkers=3, grad_walkers=3),
+    'lih_bias':      dict(system='lih', seed=23, batch=3, net_kw=dict(bias_orbitals=True), mcmc=False,
+                          ke_walkers=3, grad_walkers=3),
     # the defaults of the make_solid_fermi_net SIGNATURE (network.py:609-621), not of base_config.py
-    'lih_fn_defaults': dict(system='lih', seed=24, batch=3, mcmc=False,
+    'lih_fn_defaults': dict(system='lih', seed=24, batch=3, mcmc=False, ke_walkers=3, grad_walkers=3,
                             net_kw=dict(envelope_type='full', full_det=True, determinants=16)),
-    'bcc_li_fulldet': dict(system='bcc_li', seed=25, batch=2, net_kw=dict(full_det=True), mcmc=False),
+    'bcc_li_fulldet': dict(system='bcc_li', seed=25, batch=2, net_kw=dict(full_det=True), mcmc=False, ke_walkers=2,
+                           grad_walkers=2),
 }

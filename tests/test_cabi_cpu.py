@@ -76,3 +76,37 @@ def test_param_tree_shapes_match_reference_init():
     assert n == 531776
     with pytest.raises(ValueError):
         network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='nope')
+
+
+def test_philox_known_answers_and_moments():
+    """ds_mcmc_step's generator is Philox4x32-10 (Salmon et al., SC'11): the three known-answer vectors of the
+    Random123 distribution (kat_vectors: zeros, ones, digits of pi), and the uniform / Box-Muller maps the kernels
+    apply to the raw words (csrc/ds_mcmc.h) have the right first moments."""
+    import ctypes as C
+    from deepsolid_amd import _lib
+    lib = _lib.load()
+    out = (C.c_uint32 * 4)()
+
+    def block(c, k):            # counter words c0..c3, key words k0,k1 through the (seed, offset, index, stream) interface
+        assert c[3] < 2 ** 30
+        lib.ds_philox_host(k[0] | (k[1] << 32), c[2] | (c[3] << 32), 0, c[0] | (c[1] << 32), 0, out)
+        return [int(v) for v in out]
+    assert block([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert block([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # the offset and the step add; the stream bits separate the three draws of one (seed, offset, index)
+    lib.ds_philox_host(5, 7, 3, 11, 0, out); a = list(out)
+    lib.ds_philox_host(5, 10, 0, 11, 0, out); assert list(out) == a
+    lib.ds_philox_host(5, 10, 0, 11, 2, out); assert list(out) != a
+    n = 20000
+    words = np.zeros((n, 4), dtype=np.uint64)
+    for i in range(n):
+        lib.ds_philox_host(1234, 0, 0, i, 0, out)
+        words[i] = list(out)
+    to53 = lambda a, b: ((a << np.uint64(21)) ^ (b >> np.uint64(11))) & np.uint64(2 ** 53 - 1)
+    u1 = (to53(words[:, 0], words[:, 1]).astype(np.float64) + 1) / 2.0 ** 53
+    u2 = to53(words[:, 2], words[:, 3]).astype(np.float64) / 2.0 ** 53
+    assert 0 < u1.min() and u1.max() <= 1 and 0 <= u2.min() and u2.max() < 1
+    z = np.concatenate([np.sqrt(-2 * np.log(u1)) * np.cos(2 * np.pi * u2), np.sqrt(-2 * np.log(u1)) * np.sin(2 * np.pi * u2)])
+    assert abs(z.mean()) < 0.02 and abs(z.var() - 1) < 0.03 and abs((z ** 4).mean() - 3) < 0.15
+    assert abs(u2.mean() - 0.5) < 0.01

@@ -215,3 +215,31 @@ def test_training_loop_writes_stats_and_reference_checkpoints(tmp_path):
     x, p1, w1 = checkpoint.to_single_device(d, p, w)
     assert t == 6 and x.shape == (256, 12)
     np.testing.assert_array_equal(p1['single'][0]['w'], dp['single'][0]['w'].cpu().numpy())
+
+
+REF_GRAD_CASES = [c for c in __import__('oracle.testing', fromlist=['CASES']).CASES
+                  if __import__('oracle.testing', fromlist=['CASES']).CASES[c].get('grad_walkers')]
+
+
+@pytest.mark.parametrize('name', REF_GRAD_CASES)
+def test_energy_gradient_vs_reference_train(name):
+    """`total_energy.value_and_grad` (HIP local energy + clip + ds_logpsi_vjp) against the gradient the REFERENCE's own
+    train.make_loss / jax.value_and_grad produced (tools/make_golden.py, torch-backed jax stand-in): loss, variance,
+    every leaf's norm, its projection on a seeded direction, and the small leaves element-wise (1e-8 of the largest norm)."""
+    from deepsolid_amd import network as dnet, train
+    from oracle.testing import CASES
+    from test_oracle_golden import check_gradient_against_reference
+    fx, cell, klist, net_kw, params = load_case(name)
+    net = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    dp = dev_params(params)
+    nb = int(fx['grad_ref_walkers'])
+    x = torch.as_tensor(fx['x'][:nb], device='cuda')
+    for clip_type in CASES[name].get('grad_clip_types', ('real',)):
+        sfx = '' if clip_type == 'real' else '_' + clip_type
+        loss_fn = train.make_loss(net.apply, None, cell, clip_local_energy=5.0, clip_type=clip_type)
+        (loss, aux), g = loss_fn.value_and_grad(dp, x)
+        assert abs(float(loss) - float(fx['grad_ref_loss' + sfx])) < 1e-9 * max(1.0, abs(float(loss)))
+        assert abs(float(aux.variance) - float(fx['grad_ref_variance' + sfx])) < 1e-8 * max(1.0, float(aux.variance))
+        assert abs(float(aux.imaginary) - float(fx['grad_ref_imag' + sfx])) < 1e-9 * max(1.0, abs(float(loss)))
+        assert float(aux.n_nonfinite) == 0.0
+        check_gradient_against_reference(fx, params, g, sfx)

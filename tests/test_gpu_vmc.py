@@ -207,3 +207,78 @@ def test_inference_loop_writes_reference_csv(tmp_path):
     data2, width2, rows2 = inference.run_inference(slog, ld, dp, x0, cell, iterations=5, key=11, move_width=0.3, mcmc_steps=4,
                                                    burn_in=3, adapt_frequency=2)
     assert torch.equal(data, data2) and rows[-1]['energy'] == rows2[-1]['energy']      # reproducible from the seed
+
+
+def test_fused_mcmc_step_philox():
+    """`ds_mcmc_step` (qmc.py:335-362 as one C-ABI call, in-kernel Philox): pure function of the int key, stateful with
+    a torch.Generator, walkers stay in the cell, moves have the requested width, and the acceptance rate agrees with
+    the per-move Python loop over ds_mh_propose / ds_mh_accept driven by torch's generator (two independent noise
+    sources, 4096 x 20 decisions: |dp| < 0.02)."""
+    from deepsolid_amd import qmc, systems
+    fx, cell, klist, net_kw, params = load_case('bcc_li')
+    dp = dev_params(params)
+    (slog,) = nets(cell, klist, net_kw, 'eval_slogdet')
+    B, width, steps = 4096, 0.05, 20
+    x0 = torch.as_tensor(systems.synthetic_walkers(cell, B, seed=5), device='cuda')
+    step = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=steps)
+    xa, pa = step(dp, x0, 123, width)
+    xb, pb = step(dp, x0, 123, width)
+    xc, pc = step(dp, x0, 124, width)
+    assert torch.equal(xa, xb) and float(pa) == float(pb)          # same key -> same chain
+    assert not torch.equal(xa, xc)
+    assert 0.05 < float(pa) < 0.999 and abs(float(pa) - float(pc)) < 0.02
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    xg1, _ = step(dp, x0, gen, width)
+    xg2, _ = step(dp, x0, gen, width)
+    assert not torch.equal(xg1, xg2)                              # a Generator key advances
+    ainv = torch.linalg.inv(torch.as_tensor(cell.a, device='cuda'))
+    frac = xa.reshape(B, -1, 3) @ ainv
+    assert frac.min() > -1e-9 and frac.max() < 1 + 1e-9
+    # the per-move loop with torch noise (the generic path: atoms=None but forced through mh_update)
+    nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    x, lp = x0.clone(), 2.0 * slog.apply(dp, x0)
+    g2 = torch.Generator(device='cuda').manual_seed(77)
+    for _ in range(steps):
+        x, _, lp, nacc = qmc.mh_update(dp, slog.apply, x, g2, lp, nacc, cell.a, stddev=width)
+    p_loop = float(nacc.item()) / (steps * B)
+    assert abs(p_loop - float(pa)) < 0.02, (p_loop, float(pa))
+    # one move from identical walkers: the accepted displacements are N(0, width^2) per coordinate (minimum image)
+    one = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=1)
+    x1, p1 = one(dp, x0, 5, 0.01)
+    d = (x1 - x0).reshape(B, -1, 3) @ ainv
+    d = (d - torch.round(d)) @ torch.as_tensor(cell.a, device='cuda')
+    moved = d.abs().sum(dim=(1, 2)) > 0
+    assert abs(float(moved.double().mean()) - float(p1)) < 1e-12
+    dm = d[moved].reshape(-1)
+    assert abs(float(dm.mean())) < 2e-4 and abs(float(dm.std()) / 0.01 - 1) < 0.03
+    # explicit noise through the fused call == explicit noise through the per-move kernels
+    nz = torch.randn(3, 64, x0.shape[1], dtype=torch.float64, device='cuda', generator=g2)
+    un = torch.rand(3, 64, dtype=torch.float64, device='cuda', generator=g2)
+    s3 = qmc.make_mcmc_step(slog.apply, 64, cell.a, steps=3)
+    xf, pf = s3(dp, x0[:64], (nz, un), 0.04)
+    x, lp, nacc = x0[:64].clone(), 2.0 * slog.apply(dp, x0[:64]), torch.zeros(1, dtype=torch.float64, device='cuda')
+    for i in range(3):
+        x, _, lp, nacc = qmc.mh_update(dp, slog.apply, x, None, lp, nacc, cell.a, stddev=0.04, normal=nz[i], uniform=un[i])
+    assert torch.equal(xf, x) and float(pf) == float(nacc.item()) / (3 * 64)
+
+
+def test_energy_stats_and_nonfinite_count():
+    """ds_energy_stats: the packed vector behind total_energy (train.py:74-82) and the non-finite count."""
+    from deepsolid_amd import train
+    fx, cell, klist, net_kw, params = load_case('lih')
+    dp = dev_params(params)
+    (net,) = nets(cell, klist, net_kw, 'eval_logdet')
+    sysd = net.apply.system
+    g = torch.Generator(device='cuda').manual_seed(1)
+    ke = torch.randn(1000, 2, dtype=torch.float64, device='cuda', generator=g)
+    ew = torch.randn(1000, dtype=torch.float64, device='cuda', generator=g)
+    st = sysd.energy_stats(ke, ew).cpu().numpy()
+    e = (ke[:, 0] + ew).cpu().numpy() + 1j * ke[:, 1].cpu().numpy()
+    np.testing.assert_allclose(st, [e.real.sum(), e.imag.sum(), (np.abs(e) ** 2).sum(), 1000, 0, ke[:, 0].sum().item(),
+                                    ke[:, 1].sum().item(), ew.sum().item()], rtol=1e-12, atol=1e-10)
+    assert np.array_equal(st, sysd.energy_stats(ke, ew).cpu().numpy())         # fixed summation order
+    ke[17, 0] = float('nan'); ew[400] = float('inf')
+    st = sysd.energy_stats(ke, ew).cpu().numpy()
+    assert st[4] == 2 and st[3] == 1000 and not np.isfinite(st[0])
+    loss, aux = train.make_loss(net.apply, None, cell)(dp, torch.as_tensor(fx['x'], device='cuda'))
+    assert float(aux.n_nonfinite) == 0.0 and np.isfinite(float(loss))

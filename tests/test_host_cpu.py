@@ -238,3 +238,48 @@ def test_checkpoint_reads_reference_layout_and_round_trips(tmp_path):
     _, p3, w3 = checkpoint.to_single_device(d2, p2, w2)
     np.testing.assert_array_equal(p3['double'][0]['b'], params['double'][0]['b'])
     assert abs(w3 - 0.05) < 1e-7
+
+
+def test_adam_state_survives_a_checkpoint_round_trip(tmp_path):
+    """process.py:381 saves opt_state; a run resumed from the file must continue bit-identically to an
+    uninterrupted one (moments and the optimiser's own step count restored, no second burn-in)."""
+    import torch
+    from deepsolid_amd import checkpoint, train
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: {'single': [{'w': torch.linspace(-1, 1, 12, dtype=torch.float64).reshape(3, 4).clone(),
+                              'b': torch.zeros(4, dtype=torch.float64)}]}
+    grads = [{'single': [{'w': torch.randn(3, 4, generator=g, dtype=torch.float64),
+                          'b': torch.randn(4, generator=g, dtype=torch.float64)}]} for _ in range(6)]
+    init, update = train.adam(1e-2)
+    pa = mk(); sa = init(pa)
+    for t in range(6):
+        sa, pa = update(t, grads[t], pa, sa)
+    pb = mk(); sb = init(pb)
+    for t in range(3):
+        sb, pb = update(t, grads[t], pb, sb)
+    f = checkpoint.save(str(tmp_path), 2, torch.zeros(4, 6), pb, sb, 0.02)
+    t0, d, p, opt, w = checkpoint.restore(f, batch_size=4)
+    _, p1, _ = checkpoint.to_single_device(d, p, w)
+    opt1 = checkpoint.opt_state_to_single_device(opt)
+    assert t0 == 3 and opt1['count'] == 3
+    pc = {'single': [{k: torch.as_tensor(v) for k, v in p1['single'][0].items()}]}
+    for t in range(3, 6):
+        opt1, pc = update(t, grads[t], pc, opt1)
+    assert torch.equal(pc['single'][0]['w'], pa['single'][0]['w']) and torch.equal(pc['single'][0]['b'], pa['single'][0]['b'])
+
+
+@pytest.mark.parametrize('scaling,per_gpu', [('weak', 4096), ('strong', 2048)])
+def test_bench_launcher_spawns_one_rank_per_gpu(scaling, per_gpu):
+    """`python bench.py --gpus 2` with no launcher environment re-executes itself under torch.distributed.run;
+    both ranks report in through the all-reduce (gloo here, RCCL on the GPU node) and rank 0 prints n_gpus == 2."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--scaling', scaling],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['scaling'] == scaling
+    assert d['config']['batch_per_gpu'] == per_gpu and d['config']['global_batch'] == (4096 if scaling == 'strong' else 8192)
+    assert d['max_rank_seconds'] == pytest.approx(2e-3)            # the MAX over ranks, not rank 0's own time

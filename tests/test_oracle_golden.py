@@ -161,3 +161,117 @@ def test_oracle_parameter_gradient_vs_reference_finite_differences(name):
         for cot, key in ((1.0 + 0j, 'gradfd_dlogabs'), (1j, 'gradfd_darg')):
             g = otrain.logpsi_vjp(net.apply, params, tt(fx['x'][b:b + 1]), torch.tensor([cot]))
             assert abs(dot(g, v) - float(fx[key][b])) < 2e-7 * max(1.0, abs(float(fx[key][b])))
+
+
+# ----------------------------------------------------------------------------------------------
+# The reference's OWN hamiltonian.py / train.py, executed over its own network.py under the
+# torch-backed `jax` stand-in (tools/jax_torch_standin.py, tools/make_golden.py): ke_ref / grad_ref.
+KE_CASES = [c for c in ALL if CASES[c].get('ke_walkers')]
+GRAD_CASES = [c for c in ALL if CASES[c].get('grad_walkers')]
+CPU_GRAD_CASES = ('h2', 'lih', 'lih_fulldet', 'lih_fullenv', 'bcc_li')
+KE_TOL_HA = 1e-9          # the kinetic-energy pin of the oracle against the reference (Hartree)
+
+
+@pytest.mark.parametrize('name', KE_CASES)
+def test_kinetic_matches_reference_hamiltonian(name):
+    """oracle kinetic energy vs hamiltonian.py:45-70 run verbatim (|dE| <= 1e-9 Ha, relative above 1 Ha)."""
+    fx, cell, klist, net_kw, params = load_case(name)
+    p = onet.params_to_torch(params)
+    net = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    n = sum(cell.nelec)
+    ke_ref = fx['ke_ref']
+    assert len(ke_ref) == CASES[name]['ke_walkers']
+    default_net = not (net_kw.get('full_det', False) or net_kw.get('bias_orbitals', False)) and net_kw.get('envelope_type', 'isotropic') == 'isotropic'
+    if n <= 8:        # autodiff restatement: the reference's default schedule on one walker, `hessian` mode on the others
+        ke = oham.local_kinetic_energy_real_imag(net.apply)
+        got = [complex(sum(ke(p, tt(fx['x'][0]))))]
+        ke = oham.local_kinetic_energy_real_imag_hessian(net.apply)
+        got += [complex(sum(ke(p, tt(fx['x'][b])))) for b in range(1, len(ke_ref) if not default_net else 2)]
+    elif n <= 24:
+        ke = oham.local_kinetic_energy_real_imag_hessian(net.apply)
+        got = [complex(sum(ke(p, tt(fx['x'][b])))) for b in range(1 if default_net else 2)]
+    else:
+        got = []
+    # every walker also through the forward-Laplacian restatement (the algorithm of the HIP chain)
+    from oracle import forward_laplacian as ofl
+    assert default_net or len(got) >= min(2, len(ke_ref))     # (the forward-Laplacian oracle covers the default options)
+    for b in range(len(ke_ref) if default_net else 0):
+        v = complex(ofl.stages(p, tt(fx['x'][b]), klist, cell, net_kw)['ke'])
+        assert abs(v - ke_ref[b]) < KE_TOL_HA * max(1.0, abs(ke_ref[b])), (name, b, v, ke_ref[b])
+    for b, v in enumerate(got):
+        assert abs(v - ke_ref[b]) < KE_TOL_HA * max(1.0, abs(ke_ref[b])), (name, b, v, ke_ref[b])
+    if 'ew_ref' in fx:                                                        # the Ewald term of the same call
+        np.testing.assert_allclose(fx['ew_ref'], fx['ewald'][:len(fx['ew_ref'])].sum(-1), atol=1e-12)
+
+
+@pytest.mark.parametrize('name', [c for c in KE_CASES if len(CASES[c].get('ke_modes', ())) > 1])
+def test_reference_laplacian_modes_agree(name):
+    """hamiltonian.py `hessian` :104-124, `dim_batch` :73-101, `partition` :127-159 return the `for` number."""
+    fx = load_case(name)[0]
+    for mode in CASES[name]['ke_modes'][1:]:
+        v = fx['ke_ref_' + mode][0]
+        assert abs(v - fx['ke_ref'][0]) < 1e-10 * max(1.0, abs(v)), mode
+
+
+@pytest.mark.parametrize('name', ['lih', 'bcc_li', 'graphene'])
+def test_forward_laplacian_equals_autodiff_hessian(name):
+    """The forward-Laplacian restatement (the HIP chain's algorithm) against the autodiff `hessian`-mode
+    restatement of hamiltonian.py:104-124 — two different algorithms, so a shared mistake cannot hide."""
+    from oracle import forward_laplacian as ofl
+    fx, cell, klist, net_kw, params = load_case(name)
+    p = onet.params_to_torch(params)
+    net = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    ke = oham.local_kinetic_energy_real_imag_hessian(net.apply)
+    for b in range(1 if name == 'graphene' else 2):
+        a = complex(sum(ke(p, tt(fx['x'][b]))))
+        f = complex(ofl.stages(p, tt(fx['x'][b]), klist, cell, net_kw)['ke'])
+        assert abs(a - f) < 1e-10 * max(1.0, abs(a)), (a, f)
+
+
+def _leaves(tree, path=()):
+    if isinstance(tree, dict):
+        for k in sorted(tree):
+            yield from _leaves(tree[k], path + (k,))
+    elif isinstance(tree, (list, tuple)):
+        for i, v in enumerate(tree):
+            yield from _leaves(v, path + (i,))
+    else:
+        yield '/'.join(str(q) for q in path), tree
+
+
+def check_gradient_against_reference(fx, params, grad, sfx='', rtol=1e-8):
+    """grad (tree of torch/numpy leaves) vs the grad_ref_* records: per-leaf norm, per-leaf dot with the
+    seeded direction, and the small leaves element by element."""
+    from oracle.testing import make_test_direction
+    v = make_test_direction(int(fx['grad_ref_seed']), params)
+    names = [str(s) for s in fx['grad_ref_names']]
+    gl, vl = dict(_leaves(grad)), dict(_leaves(v))
+    assert sorted(gl) == sorted(names)
+    scale = float(np.max(fx['grad_ref_norm' + sfx]))
+    for i, nme in enumerate(names):
+        g = np.asarray(gl[nme].detach().cpu() if hasattr(gl[nme], 'detach') else gl[nme], dtype=np.float64)
+        assert abs(np.linalg.norm(g) - fx['grad_ref_norm' + sfx][i]) < rtol * scale, nme
+        assert abs(float((g * vl[nme]).sum()) - fx['grad_ref_dot' + sfx][i]) < rtol * scale * max(1.0, np.linalg.norm(vl[nme])), nme
+        key = 'grad_ref_leaf' + sfx + ':' + nme
+        if key in fx:
+            np.testing.assert_allclose(g, fx[key], atol=rtol * scale, err_msg=nme)
+
+
+@pytest.mark.parametrize('name', GRAD_CASES)
+def test_energy_gradient_matches_reference_train(name):
+    """oracle value_and_grad vs the reference's train.make_loss (:37-142) differentiated as process.py:204 does."""
+    from oracle import train as otrain
+    fx, cell, klist, net_kw, params = load_case(name)
+    if name not in CPU_GRAD_CASES:
+        pytest.skip('this fixture is checked against the HIP path in tests/test_gpu_grad.py; the CPU autodiff oracle is '
+                    'pinned on a subset to keep the CPU suite at a few minutes')
+    net = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    nb = int(fx['grad_ref_walkers'])
+    for clip_type in CASES[name].get('grad_clip_types', ('real',)):
+        sfx = '' if clip_type == 'real' else '_' + clip_type
+        loss_fn = otrain.make_loss(net.apply, cell, mode='hessian', clip_local_energy=5.0, clip_type=clip_type)
+        (loss, aux), g = loss_fn.value_and_grad(params, tt(fx['x'][:nb]))
+        assert abs(float(loss) - float(fx['grad_ref_loss' + sfx])) < 1e-9
+        assert abs(float(aux.variance) - float(fx['grad_ref_variance' + sfx])) < 1e-8 * max(1.0, float(aux.variance))
+        assert abs(float(aux.imaginary) - float(fx['grad_ref_imag' + sfx])) < 1e-9
+        check_gradient_against_reference(fx, params, g, sfx)

@@ -37,100 +37,12 @@ REF = os.environ.get('DEEPSOLID_REFERENCE', '/root/reference')
 
 
 # ----------------------------------------------------------------------------- shim
-class _Recorder:
-    """jax.random stand-in: numpy Generator whose draws are recorded."""
-    def __init__(self):
-        self.reset(0)
-
-    def reset(self, seed):
-        self.rng = np.random.default_rng(seed)
-        self.normals, self.uniforms = [], []
-
-    def split(self, key, num=2):
-        return tuple(key for _ in range(num))
-
-    def normal(self, key, shape=()):
-        v = self.rng.standard_normal(shape)
-        self.normals.append(v)
-        return v
-
-    def uniform(self, key, shape=()):
-        v = self.rng.uniform(size=shape)
-        self.uniforms.append(v)
-        return v
-
-    def PRNGKey(self, seed):
-        return np.array([0, seed], dtype=np.uint32)
-
-
-RECORDER = _Recorder()
+from tools import jax_torch_standin as standin          # noqa: E402
+from tools.jax_torch_standin import RECORDER            # noqa: E402
 
 
 def _install_shim():
-    jnp = types.ModuleType('jax.numpy')
-    for name in dir(np):
-        if not name.startswith('__'):
-            setattr(jnp, name, getattr(np, name))
-
-    def _sum(a, axis=None, **kw):
-        if isinstance(axis, list):
-            axis = tuple(axis)
-        return np.sum(a, axis=axis, **kw)
-    jnp.sum = _sum
-    jnp.DeviceArray = np.ndarray
-    jnp.linalg = np.linalg
-
-    def vmap(f, in_axes=0, out_axes=0):
-        def wrapped(*args):
-            ia = in_axes if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
-            n = next(np.shape(a)[ax] for a, ax in zip(args, ia) if ax is not None)
-            outs = [f(*[a if ax is None else np.take(a, i, axis=ax) for a, ax in zip(args, ia)])
-                    for i in range(n)]
-            if isinstance(outs[0], (tuple, list)):
-                return tuple(np.stack([o[k] for o in outs], axis=out_axes)
-                             for k in range(len(outs[0])))
-            return np.stack(outs, axis=out_axes)
-        return wrapped
-
-    def fori_loop(lo, hi, body, val):
-        for i in range(lo, hi):
-            val = body(i, val)
-        return val
-
-    lax = types.ModuleType('jax.lax')
-    lax.erfc = scipy.special.erfc
-    lax.fori_loop = fori_loop
-    lax.pmean = lambda x, axis_name=None: x
-    lax.psum = lambda x, axis_name=None: x
-
-    core = types.ModuleType('jax.core')
-
-    def axis_frame(name):
-        raise NameError(name)
-    core.axis_frame = axis_frame
-
-    rnd = types.ModuleType('jax.random')
-    for n in ('split', 'normal', 'uniform', 'PRNGKey'):
-        setattr(rnd, n, getattr(RECORDER, n))
-
-    jax = types.ModuleType('jax')
-    jax.numpy, jax.lax, jax.core, jax.random = jnp, lax, core, rnd
-    jax.vmap = vmap
-    jax.jit = lambda f, **kw: f
-    jax.pmap = lambda f, **kw: f
-    sys.modules.update({'jax': jax, 'jax.numpy': jnp, 'jax.lax': lax, 'jax.core': core,
-                        'jax.random': rnd})
-
-    tags = types.ModuleType('DeepSolid.curvature_tags_and_blocks')
-    tags.register_repeated_dense = lambda y, x, w, b: y
-    tags.register_qmc1 = lambda y, x, w, **kw: y
-    sys.modules['DeepSolid.curvature_tags_and_blocks'] = tags
-    for m in ('pyscf', 'pyscf.pbc', 'pyscf.pbc.gto'):
-        sys.modules[m] = types.ModuleType(m)
-    sys.modules['pyscf'].pbc = sys.modules['pyscf.pbc']
-    sys.modules['pyscf.pbc'].gto = sys.modules['pyscf.pbc.gto']
-    sys.modules['pyscf.pbc.gto'].Cell = object
-    sys.path.insert(0, REF)
+    standin.install(REF)
 
 
 class FakeCell:
@@ -167,6 +79,47 @@ def ref_supercell(ref_sc, prim, S, nelec):
     return ref_sc.set_symmetry_lat(sc, 'minimal')
 
 
+
+# ----------------------------------------------------------------------------- autodiff legs
+class TorchCell:
+    """The same attribute bag with torch float64 leaves: what the reference's network.py reads
+    when hamiltonian.py / train.py differentiate it under the torch-backed `jax` stand-in."""
+    def __init__(self, c, original=None, energy_nuc=None):
+        import torch
+        T = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float64))
+        self.a, self.AV, self.BV = T(c.a), T(c.AV), T(c.BV)
+        self._coords = T(c.atom_coords())
+        self.nelec = c.nelec
+        self.original_cell = original if original is not None else self
+        self.scale = c.scale
+        self._energy_nuc = energy_nuc
+
+    def atom_coords(self): return self._coords
+    def lattice_vectors(self): return self.a
+    def energy_nuc(self): return self._energy_nuc
+
+
+def to_torch_params(p):
+    import torch
+    return standin.tree_map(lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)), p)
+
+
+def flatten_leaves(tree):
+    """Leaves in the order of oracle.testing (sorted dict keys, list order)."""
+    out = []
+
+    def walk(o, path):
+        if isinstance(o, dict):
+            for k in sorted(o):
+                walk(o[k], path + (k,))
+        elif isinstance(o, (list, tuple)):
+            for i, v in enumerate(o):
+                walk(v, path + (i,))
+        else:
+            out.append(('/'.join(str(q) for q in path), o))
+    walk(tree, ())
+    return out
+
 # ----------------------------------------------------------------------------- cases
 def to_np_params(p):
     def conv(o):
@@ -200,7 +153,7 @@ def fd_kinetic(f, x, h=2e-3):
 def main():
     _install_shim()
     from DeepSolid import network as rnet, ewaldsum as rewald, distance as rdist
-    from DeepSolid import supercell as rsc, qmc as rqmc
+    from DeepSolid import supercell as rsc, qmc as rqmc, hamiltonian as rham, train as rtrain
     from deepsolid_amd import systems, supercell as my_sc
     from oracle.testing import make_test_params, params_checksum, klist_from_kpts, CASES
 
@@ -292,6 +245,69 @@ def main():
                      mcmc_uniforms=np.asarray(RECORDER.uniforms), mcmc_width=0.08, mcmc_steps=3,
                      mcmc_x_out=xs3, mcmc_pmove=float(pmove))
 
+
+        # --- kinetic energy: the reference's OWN hamiltonian.py over its own network.py -----
+        # (torch-backed jax stand-in: jax.grad/jvp/hessian -> torch.func, float64)
+        nke = case.get('ke_walkers', 0)
+        if nke:
+            import torch
+            from types import SimpleNamespace
+            from deepsolid_amd.ewaldsum import EwaldTables
+            tab = EwaldTables(my_cell)
+            e_nuc = float(tab.ion_ion + tab.ii_const)          # stands in for pyscf's cell.energy_nuc() (hamiltonian.py:170)
+            tprim = TorchCell(prim)
+            tsim = TorchCell(sim, original=tprim, energy_nuc=e_nuc)
+            tklist = [torch.as_tensor(k) for k in klist]
+            tparams = to_torch_params(pnp)
+
+            class _RefEwald:
+                """The reference's EwaldSum built on the numpy cell; only converts the walker to numpy."""
+                def __init__(self, _cell):
+                    self.ion_ion, self.ii_const = ew.ion_ion, ew.ii_const
+
+                def energy(self, xt):
+                    with standin.torch_mode(False):
+                        return [torch.as_tensor(float(v), dtype=torch.float64) for v in ew.energy(standin.to_numpy(xt))]
+            rham.ewaldsum = SimpleNamespace(EwaldSum=_RefEwald)
+            with standin.torch_mode():
+                tnet = rnet.make_solid_fermi_net(klist=tklist, simulation_cell=tsim, method_name='eval_logdet', **net_kw)
+                modes = case.get('ke_modes', ('for',))
+                for mode in modes:
+                    pn = 3 if (3 * N) % 3 == 0 else 1
+                    el = rham.local_energy_seperate(tnet.apply, tsim, mode=mode, partition_number=pn)
+                    kes, ews = [], []
+                    for b in range(nke if mode == 'for' else 1):
+                        k_, e_ = el(tparams, torch.as_tensor(x[b]))
+                        kes.append(complex(k_)); ews.append(float(e_))
+                    key = 'ke_ref' if mode == 'for' else 'ke_ref_' + mode
+                    d[key] = np.asarray(kes)
+                    if mode == 'for':
+                        d['ew_ref'] = np.asarray(ews)
+                # --- energy gradient: the reference's train.make_loss + jax.value_and_grad (process.py:191-204)
+                ngr = case.get('grad_walkers', 0)
+                if ngr:
+                    import jax
+                    batch_net = jax.vmap(tnet.apply, in_axes=(None, 0), out_axes=0)
+                    for clip_type in case.get('grad_clip_types', ('real',)):
+                        total_energy = rtrain.make_loss(network=tnet.apply, batch_network=batch_net, simulation_cell=tsim,
+                                                        clip_local_energy=5.0, clip_type=clip_type, mode='for')
+                        vg = jax.value_and_grad(total_energy, argnums=0, has_aux=True)
+                        (loss, aux), g = vg(tparams, torch.as_tensor(x[:ngr]))
+                        from oracle.testing import make_test_direction
+                        vdir = make_test_direction(case['seed'] + 600, params)
+                        gl, vl = flatten_leaves(g), flatten_leaves(vdir)
+                        sfx = '' if clip_type == 'real' else '_' + clip_type
+                        d['grad_ref_loss' + sfx] = float(loss)
+                        d['grad_ref_variance' + sfx] = float(aux.variance)
+                        d['grad_ref_imag' + sfx] = float(aux.imaginary)
+                        d['grad_ref_names'] = np.asarray([n for n, _ in gl])
+                        d['grad_ref_norm' + sfx] = np.asarray([float(torch.linalg.vector_norm(t)) for _, t in gl])
+                        d['grad_ref_dot' + sfx] = np.asarray([float((t * torch.as_tensor(v)).sum()) for (_, t), (_, v) in zip(gl, vl)])
+                        d['grad_ref_seed'] = case['seed'] + 600
+                        d['grad_ref_walkers'] = ngr
+                        for n_, t in gl:
+                            if t.numel() <= 4096:
+                                d['grad_ref_leaf' + sfx + ':' + n_] = t.numpy()
         # --- kinetic energy by finite differences of the reference-executed forward -----
         nfd = case.get('fd_walkers', 0)
         if nfd:
