@@ -90,7 +90,9 @@ def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walk
     from oracle import forward_laplacian as ofl
     from oracle import hamiltonian as oham
     from oracle import network as onet
-    cores = os.cpu_count() or 1
+    # 16 threads: the contractions of one walker are small (<= 832 x 256); on the 256-thread host of the GPU box torch's
+    # intra-op pool at full width is ~30x SLOWER than at 16 threads (measured: 46 s vs 1.5 s per loop iteration)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     net = onet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
     p = onet.params_to_torch(params_np)

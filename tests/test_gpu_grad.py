@@ -215,6 +215,15 @@ def test_training_loop_writes_stats_and_reference_checkpoints(tmp_path):
     x, p1, w1 = checkpoint.to_single_device(d, p, w)
     assert t == 6 and x.shape == (256, 12)
     np.testing.assert_array_equal(p1['single'][0]['w'], dp['single'][0]['w'].cpu().numpy())
+    # resume (process.py:120-123,381): Adam moments and step count come back, no second burn-in, last step always saved
+    opt1 = checkpoint.opt_state_to_single_device(opt)
+    assert opt1['count'] == 6 and len(opt1['m']) == len(state['m'])
+    np.testing.assert_array_equal(np.asarray(opt1['m'][0]), state['m'][0].cpu().numpy())
+    data2, dp3, state2, _, rows2 = inference.run_training(slog, logdet, dp, torch.as_tensor(x, device='cuda'), cell, iterations=2, key=3,
+                                                          burn_in=5, mcmc_steps=4, learning_rate=1e-3, save_path=str(tmp_path),
+                                                          save_every=100, t_init=t, opt_state=opt1)
+    assert [r['step'] for r in rows2] == [6, 7] and state2['count'] == 8
+    assert checkpoint.find_last_checkpoint(str(tmp_path)).endswith('qmcjax_ckpt_000007.npz')
 
 
 REF_GRAD_CASES = [c for c in __import__('oracle.testing', fromlist=['CASES']).CASES
