@@ -365,6 +365,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
         const bool res = Kh == Nout;
+        if (res && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             dim3 block; unsigned gz;
@@ -375,22 +376,22 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 // hidden layers straight from the electron rows of G (means formed on the fly)
                 ProfScope ps(s, DS_PROF_SHARED_TERM, st);
                 if (l == 0)
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 0>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
                                        (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[0], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
-                                       c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                                       c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
                 else {
                     // (its own geometry: as many waves per workgroup as possible, every workgroup re-forms the spin means)
                     dim3 sblock; unsigned sgz;
                     gemm_geom(Nout, NB, &sblock, &sgz);
                     hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, sgz), sblock, 2 * 16 * S.P * sizeof(T), st, S,
-                                       c.G[gi], blk(s->i_wsh[l]), Kh, c.ZB, Nout, S.P);
+                                       c.G[gi], blk(s->i_wsh[l]), Kh, c.ZB, Nout, S.P, blk(s->i_b[l]), 0);
                 }
             }
             {
                 // ... then the N electron tiles with the fused epilogue
                 ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
                 if (res)
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N, (unsigned)Bc, gz), block, 0, st, c.G[gi], gws, gts,
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N, (unsigned)Bc, gz), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
                                        (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
                 else
@@ -417,6 +418,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     for (int sp = 0; sp < S.nch; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
         const int Korb = Kl + (s->use_last ? S.nch * K2l : 0);
+        if (Korb % 16) return fail("orbital head with K = %d: the GEMM's operand ring needs K %% 16 == 0", Korb);
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             dim3 block; unsigned gz;
@@ -424,7 +426,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             if (s->use_last) {
                 ProfScope ps(s, DS_PROF_SHARED_TERM, st);
                 hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, gz), block, 2 * 16 * S.P * sizeof(T), st, S, c.G[gi],
-                                   blk(s->i_wsh_orb[sp]), Kl, c.ZB, OC, S.P);
+                                   blk(s->i_wsh_orb[sp]), Kl, c.ZB, OC, S.P, (const T*)nullptr, 0);
             }
             ProfScope ps(s, DS_PROF_ORBITAL, st);
             const int ch = S.mat_ch[sp];
@@ -572,17 +574,18 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         }
         if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
+        if (Kh == Nout && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         dim3 block; unsigned gz;
         gemm_geom(Nout, 4, &block, &gz);
         if (l == 0)
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 7>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
                                (const T*)nullptr, 0, vb.MEAN0, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
-                               (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                               (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
         else
             hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, gz), block, 2 * 16 * PV * sizeof(T), st, S, Gin,
-                               blk(s->i_wsh[l]), Kh, ZB, Nout, PV);
+                               blk(s->i_wsh[l]), Kh, ZB, Nout, PV, blk(s->i_b[l]), 1);
         if (Kh == Nout)
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, 0, st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, (ds::gemm_stash_bytes<T, 4, 5>(block.x)), st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
                                (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
         else
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 3>), dim3(S.N, (unsigned)ng, gz), block, 0, st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
@@ -594,12 +597,13 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
     for (int sp = 0; sp < S.nch; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
         const int Korb = Kl + (s->use_last ? S.nch * K2l : 0);
+        if (Korb % 16) return fail("orbital head with K = %d: the GEMM's operand ring needs K %% 16 == 0", Korb);
         dim3 oblock; unsigned ogz;
         gemm_geom(OC, 4, &oblock, &ogz);
         T* PHI = vb.PHI[sp]; T* Sorb = vb.SORB[sp];
         if (s->use_last)
             hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, ogz), oblock, 2 * 16 * PV * sizeof(T), st, S, Gl,
-                               blk(s->i_wsh_orb[sp]), Kl, Sorb, OC, PV);
+                               blk(s->i_wsh_orb[sp]), Kl, Sorb, OC, PV, (const T*)nullptr, 0);
         hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, Gl + (size_t)i0 * S.ldk * PV,
                            gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, PHI, (size_t)ns * OC * PV,
                            OC, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});

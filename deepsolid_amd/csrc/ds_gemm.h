@@ -30,13 +30,34 @@ template <typename T> struct OrbEpi {
     const T* bias;                  // optional orbital bias (2*nparam: Re then Im), value slot only; or null
 };
 
+// Residual stash (EPI = 2 / 4): the residual rows of a layer are rows n0..n0+16*NB-1 of the SAME tile the wave streams as
+// its B operand, and the lane that needs X[n][slot] in the epilogue is a lane that held it in its operand registers at
+// k-step n / 4.  The first stash_blocks() 16-row blocks are parked in LDS on the way (one ds_write per operand, no extra
+// global traffic); only the remaining blocks are re-read from memory in the epilogue.  Budget: half of the CU's 160 KB
+// when two workgroups share a CU (NB >= 3), 64 KB otherwise.
+template <typename T, int NB, int ST> constexpr int stash_blocks() {
+    constexpr int waves = (NB == 3 || ST > 10) ? 4 : 16 / NB;
+    constexpr int budget = (NB >= 3 ? 80 : 64) * 1024;
+    constexpr int per_block = waves * 4 * ST * 64 * (int)sizeof(T);
+    return budget / per_block > NB ? NB : budget / per_block;
+}
+template <typename T, int NB, int ST> inline size_t gemm_stash_bytes(unsigned threads) {
+    return (size_t)(threads / 64) * stash_blocks<T, NB, ST>() * 4 * ST * 64 * sizeof(T);
+}
+
+// The hidden-layer / orbital / plain-product instantiations run the four-set operand ring and need K % 16 == 0 (true for
+// every K they are launched with: hidden widths are multiples of 64, pair widths 16 or 32); layer 0 and the shared term of
+// layer 0 (K = 12, 8, ...) use the plain loop.
+__host__ __device__ constexpr bool gemm_uses_ring(int epi) { return epi == 0 || epi == 2 || epi == 4 || epi == 5; }
+
 // One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x up to 1024/NB
 // output features (grid.z walks further column blocks); every wave owns 16*NB features.  Tiles 0..n_tiles-1 use (X, W, K);
 // the optional extra tile (blockIdx.x == n_tiles) uses (X2, W2, K2): the shared spin-mean term.
 //   X  : [walker][tile][ldx rows][P]      W : [K][Nout]      Z : [walker][tile (+1)][Nout][P]
 //   EPI = 0: store the raw products Z.
-//   EPI = 1/2: fused one-electron-layer epilogue (network.py:524-528): z = Z + S + b, tanh chain rule on
-//              the jets, (EPI = 2) residual with the layer input rows, store into the next layer's G.
+//   EPI = 1/2: fused one-electron-layer epilogue (network.py:524-528): z = Z + S + b (the accumulators START at S + b, so
+//              the epilogue has nothing to load for it), tanh chain rule on the jets, (EPI = 2) residual with the layer
+//              input rows (parked in LDS during the main loop, see stash_blocks), store into the next layer's G.
 //              S : [walker][Nout][P] shared spin-mean term, Gout : [walker][tile][ldo rows][P].
 //   EPI = 3/4: value chain (slots = walkers): plain tanh(Z + S + b) without / with residual.
 //   EPI = 5: orbital head (network.py:543-557): complex phi from packed columns, M = phi * q (envelope x Bloch
@@ -59,7 +80,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         w = (q / gridDim.x) * 8 + (b & 7);
         tile = q % gridDim.x;
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // (wave-uniform values in SGPRs)
     const int lr = lane & 15, lq = lane >> 4, n0 = (blockIdx.z * (blockDim.x >> 6) + wave) * 16 * NB;
     if (n0 >= Nout) return;                      // column blocks beyond Nout (grid.z rounds up)
     const T* Xp;
@@ -74,61 +95,90 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         Wp = W2;
         nks = K2 / 4;
     }
-    Xp += (size_t)lq * P + lr;
-    Wp += (size_t)lq * Nout + n0 + lr;
+    // Xp / Wp stay wave-uniform (SGPR pairs advanced by scalar adds); the lane's place in the operand tile is a 32-bit offset
+    Wp += n0;
+    const unsigned xo = lq * P + lr, wo = lq * Nout + lr;
+    constexpr bool LAYER = EPI >= 1 && EPI <= 4, RESID = EPI == 2 || EPI == 4;
+    constexpr int NA = RESID ? stash_blocks<T, NB, ST>() : 0;          // 16-row blocks of the residual parked in LDS
+    extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
+    T* stash = reinterpret_cast<T*>(gemm_smem) + (size_t)wave * (NA * 4 * ST * 64);
     acc_t acc[NB][ST];
-#pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-        for (int s = 0; s < ST; ++s) acc[a][s] = acc_t{0, 0, 0, 0};
-    T a0[NB], b0[ST], a1[NB], b1[ST];
-#pragma unroll
-    for (int a = 0; a < NB; ++a) a0[a] = Wp[16 * a];
-#pragma unroll
-    for (int s = 0; s < ST; ++s) b0[s] = Xp[16 * s];
-    {
-        const int k1 = nks > 1 ? 1 : 0;
-#pragma unroll
-        for (int a = 0; a < NB; ++a) a1[a] = Wp[(size_t)4 * k1 * Nout + 16 * a];
-#pragma unroll
-        for (int s = 0; s < ST; ++s) b1[s] = Xp[(size_t)4 * k1 * P + 16 * s];
-    }
-    for (int ks = 0; ks < nks; ks += 2) {
-        // operands two k-steps ahead are requested before the current MFMAs are issued
-        T a2[NB], b2[ST], a3[NB], b3[ST];
-        const int k2 = ks + 2 < nks ? ks + 2 : nks - 1, k3 = ks + 3 < nks ? ks + 3 : nks - 1;
-#pragma unroll
-        for (int a = 0; a < NB; ++a) a2[a] = Wp[(size_t)4 * k2 * Nout + 16 * a];
-#pragma unroll
-        for (int s = 0; s < ST; ++s) b2[s] = Xp[(size_t)4 * k2 * P + 16 * s];
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-            for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(a0[a], b0[s], acc[a][s]);
-#pragma unroll
-        for (int a = 0; a < NB; ++a) a3[a] = Wp[(size_t)4 * k3 * Nout + 16 * a];
-#pragma unroll
-        for (int s = 0; s < ST; ++s) b3[s] = Xp[(size_t)4 * k3 * P + 16 * s];
-        if (ks + 1 < nks) {
-#pragma unroll
-            for (int a = 0; a < NB; ++a)
-#pragma unroll
-                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(a1[a], b1[s], acc[a][s]);
-        }
-#pragma unroll
-        for (int a = 0; a < NB; ++a) { a0[a] = a2[a]; a1[a] = a3[a]; }
-#pragma unroll
-        for (int s = 0; s < ST; ++s) { b0[s] = b2[s]; b1[s] = b3[s]; }
-    }
-    if (EPI == 0) {
-        T* Zp = Z + (size_t)w * z_walker_stride + (size_t)tile * Nout * P;
+    if (LAYER) {
+        // z = W x + (S + b): the accumulators start at the shared spin-mean term, which already carries the bias
+        // (EPI = 6 / 7 below, k_shared_term); these loads overlap the first operand loads
+        const T* Sp0 = Sb + (size_t)w * Nout * P + lr;
 #pragma unroll
         for (int a = 0; a < NB; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 16 * a + acc_row<T>(lane, r);
 #pragma unroll
-                for (int s = 0; s < ST; ++s) Zp[(size_t)n * P + 16 * s + lr] = acc[a][s][r];
+                for (int s = 0; s < ST; ++s) acc[a][s][r] = Sp0[n * P + 16 * s];
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int s = 0; s < ST; ++s) acc[a][s] = acc_t{0, 0, 0, 0};
+    }
+    // Operand ring of four k-steps: set u holds the operands of k-step ks + u; as soon as its MFMAs are issued the set is
+    // reloaded for k-step ks + u + 4.  Loads are therefore requested three k-steps (60 MFMAs) before they are needed,
+    // with no register copies at the loop end (the 4x unrolled body renames the sets).
+    T av[4][NB], bv[4][ST];
+    const T* Wl = Wp + wo;                  // this lane's operands of the next k-step to request
+    const T* Xl = Xp + xo;
+    const size_t wstep = (size_t)4 * Nout, xstep = (size_t)4 * P;
+    auto load_set = [&](int u) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a) av[u][a] = Wl[16 * a];
+#pragma unroll
+        for (int s = 0; s < ST; ++s) bv[u][s] = Xl[16 * s];
+        Wl += wstep;
+        Xl += xstep;
+    };
+    auto step = [&](int u, int k) {
+        if (NA > 0) {                    // k-steps n0/4 .. n0/4 + 4*NA - 1 carry this wave's residual rows: park the operands
+            const int j = k - (n0 >> 2);
+            if (j >= 0 && j < 4 * NA) {
+#pragma unroll
+                for (int s = 0; s < ST; ++s) stash[(j * ST + s) * 64 + lane] = bv[u][s];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
+    };
+    // (compile-time choice: the launcher guarantees K % 16 == 0 for the ring instantiations -- gemm_ring_ok)
+    if (gemm_uses_ring(EPI)) {
+        // every load of the steady state is unconditional, so the outstanding-load count is the same on every path and the
+        // waits stay partial (vmcnt(27)): a conditional reload would force a full drain at the loop head
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_set(u);
+        int ks = 0;
+        for (; ks + 4 < nks; ks += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { step(u, ks + u); load_set(u); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) step(u, ks + u);
+    } else {
+        // short contractions (layer 0: K = 12, 8): one set, no ring
+        for (int ks = 0; ks < nks; ++ks) { load_set(0); step(0, ks); }
+    }
+    if (EPI == 0 || EPI == 6 || EPI == 7) {
+        // EPI 6 / 7: the shared term of a layer, stored WITH the layer's bias (6: on the value slot of the jets,
+        // 7: on every walker column of the value chain), so the consuming GEMM starts its accumulators at S + b
+        T* Zp = Z + (size_t)w * z_walker_stride + (size_t)tile * Nout * P;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * a + acc_row<T>(lane, r);
+                const T bn = EPI == 0 ? T(0) : bias[n];
+#pragma unroll
+                for (int s = 0; s < ST; ++s)
+                    Zp[(size_t)n * P + 16 * s + lr] = acc[a][s][r] + ((EPI == 7 || (EPI == 6 && s == 0 && lr == 0)) ? bn : T(0));
             }
     } else if (EPI == 5) {
         const int i = oe.i0 + tile, so = 2 + 3 * i, base = lane & 48;
@@ -187,59 +237,78 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     } else {
         // Z here is the next layer's G: [walker][tile][x_tile_stride / P rows][P] (same geometry as X)
         const T rs2 = T(0.70710678118654752440);
-        const T* Sp = Sb + (size_t)w * Nout * P + lr;
         const T* Gi = X + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
         T* Go = Z + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
-        const int base = lane & 48;
-        // the rows of the epilogue are independent: the S / residual / bias loads of row q + DEPTH are requested
-        // before row q is worked on, so their latency (L2 for S, HBM for the residual) overlaps the arithmetic
-        constexpr int NQ = NB * 4, DEPTH = 2;
-        T zq[DEPTH + 1][ST], hq[DEPTH + 1][ST], bq[DEPTH + 1];
+        // Row groups q = 4a + r (4 rows x P slots each) are independent.  The residual of the first NQL groups comes from
+        // the LDS stash; the others are re-read from memory, up to DEPTH groups in flight, and those loads are issued
+        // before the stash rows are worked on, so their latency overlaps that arithmetic.
+        constexpr int NQ = NB * 4, NQL = NA * 4, NQG = RESID ? NQ - NQL : 0, DMAX = 40 / (ST * (int)sizeof(T) / 4) > 1 ? 40 / (ST * (int)sizeof(T) / 4) : 1,
+                      DEPTH = NQG < DMAX ? NQG : DMAX;      // about 40 VGPRs of loads in flight
+        T hq[DEPTH > 0 ? DEPTH : 1][ST];
         auto fetch = [&](int q, int slot) {
             const int n = n0 + 16 * (q >> 2) + acc_row<T>(lane, q & 3);
 #pragma unroll
-            for (int s = 0; s < ST; ++s) zq[slot][s] = Sp[(size_t)n * P + 16 * s];
-            if (EPI == 2 || EPI == 4) {
-#pragma unroll
-                for (int s = 0; s < ST; ++s) hq[slot][s] = Gi[(size_t)n * P + 16 * s];
-            }
-            bq[slot] = bias[n];
+            for (int s = 0; s < ST; ++s) hq[slot][s] = Gi[n * P + 16 * s];
         };
 #pragma unroll
-        for (int q = 0; q < DEPTH && q < NQ; ++q) fetch(q, q % (DEPTH + 1));
+        for (int g = 0; g < DEPTH; ++g) fetch(NQL + g, g);
+        if (NA > 0) {      // the stash is read by the wave that wrote it (f32: by another lane of it): order LDS within the wave
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // tanh of the NQ <= 16 value slots in ONE evaluation: lane lr of every 16-lane row takes row group q = lr (its
+        // value slot sits in lane 0 of the row), the results go back with row broadcasts
+        T yall = 0;
+        if (EPI < 3) {
+            T zsel = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const T v = row16_bcast<0>(acc[q >> 2][0][q & 3]);
+                zsel = lr == q ? v : zsel;
+            }
+            yall = ds_tanh(zsel);
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            if (q + DEPTH < NQ) fetch(q + DEPTH, (q + DEPTH) % (DEPTH + 1));
-            const int a = q >> 2, r = q & 3, cur = q % (DEPTH + 1);
+            const int a = q >> 2, r = q & 3;
             const int n = n0 + 16 * a + acc_row<T>(lane, r);
-            T(&z)[ST] = zq[cur];
-            T(&hv)[ST] = hq[cur];
-            const T bn = bq[cur];
-            T ss = 0;
+            T z[ST], hv[ST];
+#pragma unroll
+            for (int s = 0; s < ST; ++s) z[s] = acc[a][s][r];
+            if (RESID) {
+                if (q < NQL) {
+                    const int rr = 16 * a + acc_row<T>(lane, r);       // row of the wave's block: k-step rr / 4, operand lane group rr % 4
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) hv[s] = stash[((rr >> 2) * ST + s) * 64 + ((rr & 3) << 4) + lr];
+                } else {
+                    const int slot = (q - NQL) % (DEPTH > 0 ? DEPTH : 1);
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) hv[s] = hq[slot][s];
+                    if (q + DEPTH < NQ) fetch(q + DEPTH, slot);
+                }
+            }
             if (EPI >= 3) {
 #pragma unroll
                 for (int s = 0; s < ST; ++s) {
-                    T o = ds_tanh(z[s] + acc[a][s][r] + bn);
+                    T o = ds_tanh(z[s]);
                     if (EPI == 4) o = (hv[s] + o) * rs2;
-                    Go[(size_t)n * P + 16 * s] = o;
+                    Go[n * P + 16 * s] = o;
                 }
                 continue;
             }
+            T ss = 0;
 #pragma unroll
-            for (int s = 0; s < ST; ++s) {
-                z[s] += acc[a][s][r];
+            for (int s = 0; s < ST; ++s)
                 if (16 * s + lr >= 2) ss += z[s] * z[s];
-            }
-            if (lr == 0) z[0] += bn;
             ss = row16_sum(ss);
-            const T z0 = row16_bcast<0>(z[0]), zL = row16_bcast<1>(z[0]);
-            const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
+            const T zL = row16_bcast<1>(z[0]);
+            const T y = row16_bcast_dyn<NQ>(yall, q), d1 = 1 - y * y, d2 = -2 * y * d1;
 #pragma unroll
             for (int s = 0; s < ST; ++s) {
                 T o = d1 * z[s];
                 if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
                 if (EPI == 2) o = (hv[s] + o) * rs2;
-                Go[(size_t)n * P + 16 * s] = o;
+                Go[n * P + 16 * s] = o;
             }
         }
     }
@@ -251,7 +320,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 // LDS (each thread sums 32-byte pieces of the rows, fully coalesced), then every wave runs 4 k-steps on it.
 template <typename T, int NB, int ST>
 __global__ void __launch_bounds__(1024 / NB, (NB == 4 ? 2 : 1))
-k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, int Kh, T* __restrict__ Sb, int Nout, int P) {
+k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, int Kh, T* __restrict__ Sb, int Nout, int P,
+              const T* __restrict__ bias, int bias_all_slots) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int KC = 16;
     extern __shared__ __attribute__((aligned(32))) char smem_raw[];
@@ -308,8 +378,9 @@ k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + 16 * a + acc_row<T>(lane, r);
+            const T bn = bias ? bias[n] : T(0);        // the layer bias rides on S (value slot of the jets / every walker column)
 #pragma unroll
-            for (int s = 0; s < ST; ++s) Sp[(size_t)n * P + 16 * s + lr] = acc[a][s][r];
+            for (int s = 0; s < ST; ++s) Sp[(size_t)n * P + 16 * s + lr] = acc[a][s][r] + ((bias_all_slots || (s == 0 && lr == 0)) ? bn : T(0));
         }
 }
 
