@@ -509,7 +509,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
 template <typename T> struct ValBufs {
     T* Gl[DS_MAX_LAYERS + 1];
     T* H2l[DS_MAX_LAYERS + 1];
-    T *MEAN0, *ZB, *Q, *MOUT, *DETS;
+    T *MEAN0, *MEANS, *ZB, *Q, *MOUT, *DETS;     // MEANS: spin means of a hidden layer's input (scratch of k_spin_mean)
     T* PHI[2];              // orbital GEMM output per spin channel (the plain pass reuses ZB for both)
     T* SORB[2];             // use_last_layer: shared term of the orbital head
     T* MINV;                // optional inverses, laid out like MOUT (walker-interleaved)
@@ -530,6 +530,7 @@ ValBufs<T> carve_value(ds_system* s, void* ws, int64_t ng) {
     b.MOUT = p; p += L.MOUT * ng;
     b.DETS = p; p += L.DETS * ng;
     b.MEAN0 = MEAN[0];
+    b.MEANS = MEAN[1];
     for (int l = 0; l <= S.n_layers; ++l) { b.Gl[l] = G[l & 1]; b.H2l[l] = H2[l & 1]; }
     for (int sp = 0; sp < 2; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn;
@@ -581,9 +582,14 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 7>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
                                (const T*)nullptr, 0, vb.MEAN0, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
                                (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
-        else
-            hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, gz), block, 2 * 16 * PV * sizeof(T), st, S, Gin,
-                               blk(s->i_wsh[l]), Kh, ZB, Nout, PV, blk(s->i_b[l]), 1);
+        else {
+            // hidden layers: spin means over the electrons in a bandwidth-bound pass that fills the chip (a group is one
+            // workgroup's worth of GEMM), then the shared term as a K = nch*Kh product on them
+            hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)((Ksh * PV + 255) / 256), (unsigned)ng), dim3(256), 0, st, S, Gin, Kh, vb.MEANS);
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 7>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
+                               (const T*)nullptr, 0, vb.MEANS, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
+                               (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
+        }
         if (Kh == Nout)
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, (ds::gemm_stash_bytes<T, 4, 5>(block.x)), st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
                                (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
@@ -615,6 +621,14 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         const size_t dstride = s->ws.DETS;
         for (int sp = 0; sp < S.n_detch; ++sp) {
             const int n = S.det_n[sp];
+            if (!vb.MINV && n <= 16) {              // log det only: register LU, four lanes per matrix
+                const dim3 lgrid(S.K, (unsigned)((Bc + 63) / 64));
+#define DS_LU(RV) hipLaunchKernelGGL((ds::k_det_lu_val<T, RV>), lgrid, dim3(256), 0, st, S, MOUT, L.MOUT, L.mout_off[sp], sp, (long)Bc, DETS, dstride, \
+                                     s->ws.dets_off[sp])
+                if (n <= 4) DS_LU(1); else if (n <= 8) DS_LU(2); else if (n <= 12) DS_LU(3); else DS_LU(4);
+#undef DS_LU
+                continue;
+            }
             size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
             hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, MOUT, L.MOUT, L.mout_off[sp], sp,
                                vb.MINV, L.MOUT, L.mout_off[sp], DETS, dstride, s->ws.dets_off[sp], PV, PV, PV, PV);
@@ -828,6 +842,7 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
         for (int l = S.n_double + 1; l <= L; ++l) vb.H2l[l] = vb.H2l[S.n_double];
         vb.MEAN0 = p; p += V.MEAN * ng;
         T* MEANL = p; p += V.MEAN * ng;
+        vb.MEANS = MEANL;                         // forward scratch; the reverse sweep refills it layer by layer
         T* MEANBAR = p; p += V.MEAN * ng;
         vb.ZB = p; p += V.ZB * ng;
         vb.Q = p; p += V.Q * ng;

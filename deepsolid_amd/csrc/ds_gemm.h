@@ -150,7 +150,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
             for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
     };
     // (compile-time choice: the launcher guarantees K % 16 == 0 for the ring instantiations -- gemm_ring_ok)
-    if (gemm_uses_ring(EPI)) {
+    if (gemm_uses_ring(EPI) || ((EPI == 6 || EPI == 7) && (nks & 3) == 0)) {      // (EPI 6 / 7: the long shared-term products too)
         // every load of the steady state is unconditional, so the outstanding-load count is the same on every path and the
         // waits stay partial (vmcnt(27)): a conditional reload would force a full drain at the loop head
 #pragma unroll
@@ -206,14 +206,13 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 Cx<T> fo[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
+                    // slot sl = so + c of this row: pick its slot tile first (st is workgroup-uniform), then ONE cross-lane read
                     const int sl = so + c, st = sl >> 4, src = base | (sl & 15);
-                    T re = 0, im = 0;
+                    T re = phi[0].re, im = phi[0].im;
 #pragma unroll
-                    for (int s = 0; s < ST; ++s) {
-                        const T tr = __shfl(phi[s].re, src), ti = __shfl(phi[s].im, src);
-                        if (s == st) { re = tr; im = ti; }
-                    }
-                    fo[c] = Cx<T>(re, im);
+                    for (int s = 1; s < ST; ++s)
+                        if (s == st) { re = phi[s].re; im = phi[s].im; }
+                    fo[c] = Cx<T>(__shfl(re, src), __shfl(im, src));
                 }
                 const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
                 if (valid) {

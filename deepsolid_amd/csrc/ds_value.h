@@ -174,6 +174,86 @@ __global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __r
     }
 }
 
+// log-determinant of every (walker, det) matrix of one determinant channel WITHOUT the inverse (Metropolis / log psi only):
+// LU with partial pivoting, FOUR LANES PER MATRIX -- lane p of a quad keeps rows R*p .. R*p+R-1 in registers (n <= 4R <= 16),
+// so a wave factorises 16 walkers' matrices at once with no LDS and no barriers.  The 16 walkers of a wave are consecutive
+// columns of one group: every load is four 128-byte segments.  Pivoting is implicit (no row exchanges): step k takes the
+// largest |a[r][k]| among the rows not used yet, its owner broadcasts the row inside the quad, every other unused row is
+// reduced; det = sgn(order) * prod pivots, the sign from the number of unused rows skipped at each step.
+// Rows / columns n .. 4R-1 are padded with the identity.  Replaces jnp.linalg.slogdet at network.py:390 for the value chain.
+// grid (K, ceil(B / 64)), block 256 (4 waves x 16 walkers).
+template <typename T, int R>
+__global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off, int sp,
+                                                    long B, T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+    constexpr int NC = 4 * R;
+    const int kdet = blockIdx.x, lane = threadIdx.x & 63, p = lane & 3;
+    const long w = ((long)blockIdx.y * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
+    const long wc = w < B ? w : B - 1;                   // the tail repeats the last walker (never stored)
+    const int n = S.det_n[sp];
+    const T* Mw = MOUT + (size_t)(wc / PV) * mout_stride + mout_off + (size_t)kdet * n * n * 2 * PV + wc % PV;
+    Cx<T> a[R][NC];
+#pragma clang loop unroll(full)
+    for (int rr = 0; rr < R; ++rr) {
+        const int r = R * p + rr;
+#pragma clang loop unroll(full)
+        for (int m = 0; m < NC; ++m) {
+            if (r < n && m < n) a[rr][m] = Cx<T>(Mw[(size_t)((r * n + m) * 2) * PV], Mw[(size_t)((r * n + m) * 2 + 1) * PV]);
+            else a[rr][m] = Cx<T>(r == m ? T(1) : T(0), T(0));
+        }
+    }
+    unsigned used = 0;                                     // bit r: row r has been a pivot (the same in the four lanes)
+    T logabs = 0;
+    Cx<T> ph(1, 0);
+    const int qbase = lane & ~3;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < NC; ++k) {
+        T best = -1;
+        int bi = NC;
+#pragma clang loop unroll(full)
+        for (int rr = 0; rr < R; ++rr) {
+            const int r = R * p + rr;
+            const T m2 = cx_abs2(a[rr][k]);
+            if (!((used >> r) & 1u) && m2 > best) { best = m2; bi = r; }
+        }
+#pragma clang loop unroll(full)
+        for (int off = 1; off < 4; off <<= 1) {            // quad maximum, ties to the lower row
+            const T ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        const int owner = qbase | (bi / R), orr = bi % R;
+        if (__popc(~used & ((1u << bi) - 1u)) & 1) ph = Cx<T>(-ph.re, -ph.im);      // unused rows skipped: parity of the order
+        used |= 1u << bi;
+        Cx<T> pv[NC];
+#pragma clang loop unroll(full)
+        for (int m = k; m < NC; ++m) {
+            Cx<T> mine = a[0][m];
+#pragma clang loop unroll(full)
+            for (int rr = 1; rr < R; ++rr)
+                if (orr == rr) mine = a[rr][m];
+            pv[m] = Cx<T>(__shfl(mine.re, owner), __shfl(mine.im, owner));
+        }
+        const T ad = ds_sqrt(cx_abs2(pv[k]));
+        logabs += ds_log(ad);
+        ph = ph * Cx<T>(pv[k].re / ad, pv[k].im / ad);
+        const Cx<T> dinv = cx_inv(pv[k]);
+#pragma clang loop unroll(full)
+        for (int rr = 0; rr < R; ++rr) {
+            const int r = R * p + rr;
+            if (!((used >> r) & 1u)) {
+                const Cx<T> f = a[rr][k] * dinv;
+                const Cx<T> nf(-f.re, -f.im);
+#pragma clang loop unroll(full)
+                for (int m = k + 1; m < NC; ++m) a[rr][m] = cx_fma(nf, pv[m], a[rr][m]);
+            }
+        }
+    }
+    if (p == 0 && w < B) {
+        T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
+        dw[0] = logabs;
+        dw[1] = ds_atan2(ph.im, ph.re);
+    }
+}
+
 // M = phi * q (values).  PHI [group][elec in spin][ocols][PV], grid (n_s, groups), block 256
 template <typename T>
 __global__ void __launch_bounds__(256) k_orbital_epilogue_val(SysDev<T> S, const T* __restrict__ PHI, size_t phi_group_stride,
