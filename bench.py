@@ -62,6 +62,21 @@ def pmc_traffic(kernel_prefix):
     return best
 
 
+def pmc_clock(kernel_prefix):
+    """Shader clock while the dominant kernel runs, from the committed GRBM_GUI_ACTIVE pass (tools/pmc_clock.sh: cycles summed
+    over the 8 XCDs / kernel duration / 8); None if no profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_clock.json'))):
+        try:
+            for name, e in json.load(open(f)).items():
+                if name.startswith(kernel_prefix) and e.get('clock_ghz'):
+                    best = dict(clock_ghz=e['clock_ghz'] / 8.0, source=os.path.basename(f))
+        except Exception:
+            pass
+    return best
+
+
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
@@ -101,7 +116,8 @@ def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walk
     xs = torch.as_tensor(x_np[:nw])
     n3 = xs.shape[1]
     one_dir = vmap(lambda xx: oham.local_kinetic_energy_real_imag(net.apply, directions=1)(p, xx)[0])
-    t0 = time.perf_counter(); one_dir(xs[:2]); t_probe = time.perf_counter() - t0       # warm-up, and a cost probe
+    one_dir(xs[:2])                                                                      # warm-up (first-call overheads)
+    t0 = time.perf_counter(); one_dir(xs[:2]); t_probe = time.perf_counter() - t0       # cost probe on two walkers
     if t_probe * nw / 2 * 3 > 2 * seconds:                # keep the whole sample near `seconds`
         nw = max(2, int(nw * seconds / (t_probe * nw / 2 * 3)))
         xs = xs[:nw]
@@ -179,6 +195,7 @@ def main():
                     help='weak: every rank keeps --batch walkers (default); strong: --batch walkers are split across the ranks')
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-mcmc', action='store_true', help='skip the (untimed, reported separately) Metropolis sub-benchmark')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend ('nccl' is RCCL on ROCm; 'gloo' only for the launcher test on CPU hosts)")
@@ -244,6 +261,31 @@ def main():
     prof_all = sysd.profile_read()
     sysd.profile(False)
     log(f'{args.steps} steps in {dt:.3f} s; kernels: ' + ', '.join(f'{k}={v[0]:.1f}ms' for k, v in prof_all.items()))
+    mcmc = None
+    if not args.no_mcmc:
+        # Metropolis sub-benchmark (width 0.02, 20 moves = base_config.py:110,116), outside the timed region:
+        # one `ds_mcmc_step` call = 21 log|psi| forwards of the whole batch, in-kernel Philox noise
+        from deepsolid_amd import qmc
+        slog = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', dtype=dtype, **net_kw)
+        step = qmc.make_mcmc_step(slog.apply, args.batch, cell.a, steps=20)
+        xm, pm = step(params, x, 11 + rank, 0.02)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 3
+        e0.record()
+        for r in range(reps):
+            xm, pm = step(params, xm, 100 + r, 0.02)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        e0.record()
+        for r in range(reps):
+            lp = slog.apply(params, xm)
+        e1.record()
+        torch.cuda.synchronize()
+        mcmc = {'ms_per_mcmc_step': ms, 'moves': 20, 'width': 0.02, 'pmove': float(pm), 'logpsi_forward_ms': e0.elapsed_time(e1) / reps,
+                'walker_moves_per_s': world * args.batch * 20 / (ms * 1e-3)}
+        log(f"mcmc_step (20 moves, {args.batch} walkers): {ms:.1f} ms, log-psi forward {mcmc['logpsi_forward_ms']:.2f} ms, pmove {float(pm):.3f}")
     ranks_seen = 1
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -285,7 +327,16 @@ def main():
                      # datasheet rate is reachable with VGPR accumulators (51.5 TFLOP/s with AGPR accumulators); `frac` uses `peak`
                      'instruction_rate': {'v_mfma_f64_16x16x4_f64': 77.7, 'unit': 'TFLOP/s'} if dtype == torch.float64 else None},
         'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},     # from one extra untimed step
+        'mcmc': mcmc,
     }
+    clk = pmc_clock('ds::k_jet_gemm<double, 4, 5, 2>') if (args.system == 'bcc_li' and dtype == torch.float64) else None
+    if clk:
+        # the chip does not hold its 2.4 GHz boost clock under this kernel (power): the MFMA peak AT THE MEASURED CLOCK is
+        # peak * clock / 2.4; `frac` above stays relative to the datasheet peak
+        out['roofline']['shader_clock_ghz'] = clk['clock_ghz']
+        out['roofline']['clock_source'] = clk['source']
+        out['roofline']['peak_at_measured_clock'] = peak * clk['clock_ghz'] / 2.4
+        out['roofline']['frac_at_measured_clock'] = achieved / (peak * clk['clock_ghz'] / 2.4)
     if args.system == 'bcc_li' and dtype == torch.float64:
         tr = pmc_traffic('ds::k_jet_gemm<double, 4, 5, 2>')
         if tr:

@@ -45,6 +45,14 @@ template <typename T, int NB, int ST> inline size_t gemm_stash_bytes(unsigned th
     return (size_t)(threads / 64) * stash_blocks<T, NB, ST>() * 4 * ST * 64 * sizeof(T);
 }
 
+// Depth of the operand ring: as many k-steps of operands as the register file leaves next to the accumulators (256 VGPRs per
+// wave with two waves per SIMD, 512 for the four-wave workgroups of the widest tiles), at most four, at least two.
+template <typename T, int NB, int ST> constexpr int ring_sets() {
+    constexpr int vg = (int)sizeof(T) / 4, limit = (NB == 1 || ST > 10) ? 512 : 256;
+    constexpr int n = (limit - NB * ST * 4 * vg - 24) / ((NB + ST) * vg);
+    return n > 4 ? 4 : (n < 2 ? 2 : n);
+}
+
 // The hidden-layer / orbital / plain-product instantiations run the four-set operand ring and need K % 16 == 0 (true for
 // every K they are launched with: hidden widths are multiples of 64, pair widths 16 or 32); layer 0 and the shared term of
 // layer 0 (K = 12, 8, ...) use the plain loop.
@@ -124,7 +132,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     // Operand ring of four k-steps: set u holds the operands of k-step ks + u; as soon as its MFMAs are issued the set is
     // reloaded for k-step ks + u + 4.  Loads are therefore requested three k-steps (60 MFMAs) before they are needed,
     // with no register copies at the loop end (the 4x unrolled body renames the sets).
-    T av[4][NB], bv[4][ST];
+    constexpr int NSET = ring_sets<T, NB, ST>();
+    T av[NSET][NB], bv[NSET][ST];
     const T* Wl = Wp + wo;                  // this lane's operands of the next k-step to request
     const T* Xl = Xp + xo;
     const size_t wstep = (size_t)4 * Nout, xstep = (size_t)4 * P;
@@ -149,19 +158,37 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 #pragma unroll
             for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
     };
-    // (compile-time choice: the launcher guarantees K % 16 == 0 for the ring instantiations -- gemm_ring_ok)
+    // (compile-time choice: the launcher guarantees K % 16 == 0 for the ring instantiations -- gemm_uses_ring)
     if (gemm_uses_ring(EPI) || ((EPI == 6 || EPI == 7) && (nks & 3) == 0)) {      // (EPI 6 / 7: the long shared-term products too)
         // every load of the steady state is unconditional, so the outstanding-load count is the same on every path and the
         // waits stay partial (vmcnt(27)): a conditional reload would force a full drain at the loop head
 #pragma unroll
-        for (int u = 0; u < 4; ++u) load_set(u);
+        for (int u = 0; u < NSET; ++u) load_set(u);       // (nks >= 4 >= NSET)
         int ks = 0;
-        for (; ks + 4 < nks; ks += 4) {
+        if (NSET == 4) {
+            for (; ks + 4 < nks; ks += 4) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { step(u, ks + u); load_set(u); }
+                for (int u = 0; u < 4; ++u) { step(u, ks + u); load_set(u); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) step(u, ks + u);
+        } else {
+            // fewer sets (wide slot ranges: the accumulators leave room for two or three): nks need not divide, the last
+            // one or two rounds reload conditionally
+            for (; ks + 2 * NSET <= nks; ks += NSET) {
+#pragma unroll
+                for (int u = 0; u < NSET; ++u) { step(u, ks + u); load_set(u); }
+            }
+#pragma unroll
+            for (int u = 0; u < NSET; ++u) {
+                step(u, ks + u);
+                if (ks + u + NSET < nks) load_set(u);
+            }
+            ks += NSET;
+#pragma unroll
+            for (int u = 0; u < NSET; ++u)
+                if (ks + u < nks) step(u, ks + u);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) step(u, ks + u);
     } else {
         // short contractions (layer 0: K = 12, 8): one set, no ring
         for (int ks = 0; ks < nks; ++ks) { load_set(0); step(0, ks); }
