@@ -117,4 +117,9 @@ CASES = {
                             net_kw=dict(envelope_type='full', full_det=True, determinants=16)),
     'bcc_li_fulldet': dict(system='bcc_li', seed=25, batch=2, net_kw=dict(full_det=True), mcmc=False, ke_walkers=2,
                            grad_walkers=2),
+    # the non-minimal feature lattices of supercell.set_symmetry_lat (:103-129): 4 rows of AV/BV (fcc, hexagonal), 6 rows (bcc)
+    'lih_fcc':       dict(system='lih', seed=27, batch=3, sym_type='fcc', mcmc=False, ke_walkers=3, grad_walkers=3),
+    'graphene_hex':  dict(system='graphene', seed=28, batch=2, system_kw=dict(S=1), sym_type='hexagonal', mcmc=False,
+                          ke_walkers=2, grad_walkers=2),
+    'bcc_li_bcc':    dict(system='bcc_li', seed=29, batch=2, sym_type='bcc', mcmc=False, ke_walkers=2),
 }

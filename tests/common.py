@@ -17,6 +17,9 @@ def load_case(name):
     case = CASES[name]
     cell, klist = systems.build(case['system'], twist=case.get('twist', (0, 0, 0)),
                                 **case.get('system_kw', {}))
+    if case.get('sym_type'):
+        from deepsolid_amd import supercell
+        supercell.set_symmetry_lat(cell, case['sym_type'])
     net_kw = dict(systems.DETNET_DEFAULTS)
     net_kw.update(case.get('net_kw', {}))
     params = make_test_params(case['seed'], cell.original_cell.atom_coords(), cell.nelec, net_kw)

@@ -150,7 +150,10 @@ def test_stages_vs_forward_laplacian_oracle(name):
 OPTION_CASES = ['lih_lastlayer', 'lih_tri', 'lih_fulldet', 'lih_diagenv', 'lih_fullenv', 'lih_bias', 'lih_fn_defaults', 'bcc_li_fulldet']
 
 
-@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'] + OPTION_CASES)
+SYM_CASES = ['lih_fcc', 'graphene_hex', 'bcc_li_bcc']      # feature lattices with 4 and 6 rows (supercell.py:103-129)
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'] + OPTION_CASES + SYM_CASES)
 def test_logpsi_and_orbitals_vs_reference_vectors(name):
     from deepsolid_amd import network
     fx, cell, klist, net_kw, params = load_case(name)

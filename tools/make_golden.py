@@ -63,7 +63,7 @@ class FakeCell:
     def atom_charges(self): return self._charges
 
 
-def ref_supercell(ref_sc, prim, S, nelec):
+def ref_supercell(ref_sc, prim, S, nelec, sym_type='minimal'):
     """reference supercell.get_supercell (:64-95) minus the PySCF build()."""
     S = np.asarray(S, float)
     Rpts = ref_sc.get_supercell_copies(prim.lattice_vectors(), S)
@@ -76,7 +76,7 @@ def ref_supercell(ref_sc, prim, S, nelec):
     sc.original_cell = prim
     sc.S = S
     sc.scale = abs(int(np.round(np.linalg.det(S))))
-    return ref_sc.set_symmetry_lat(sc, 'minimal')
+    return ref_sc.set_symmetry_lat(sc, sym_type)
 
 
 
@@ -168,7 +168,7 @@ def main():
         prim0 = my_cell.original_cell
         # rebuild the cell with the REFERENCE's supercell code from primitive data only
         prim = FakeCell(prim0.a, prim0.atom_coords(), prim0.atom_charges(), prim0.nelec)
-        sim = ref_supercell(rsc, prim, my_cell.S, my_cell.nelec)
+        sim = ref_supercell(rsc, prim, my_cell.S, my_cell.nelec, case.get('sym_type', 'minimal'))
         kpts = rsc.get_supercell_kpts(sim)
         twist = np.asarray(case.get('twist', (0, 0, 0)), float)
         kpts_t = kpts + np.dot(np.linalg.inv(prim.a), np.mod(twist, 1.0)) * 2 * np.pi   # hf.py:61-62
