@@ -88,14 +88,48 @@ def make_klist(simulation_cell, twist=(0.0, 0.0, 0.0)):
     (reference hf.py:61-62 for the twist shift, :99-104 for the grouping):
     k-points are filled in order, each repeated by its occupation, so that
     every spin channel gets exactly ``n_s`` rows."""
-    prim = simulation_cell.original_cell
     kpts = get_supercell_kpts(simulation_cell)
-    kpts = kpts + np.dot(np.linalg.inv(prim.a), np.mod(np.asarray(twist, dtype=np.float64), 1.0)) * 2 * np.pi
+    # hf.py:61: the twist is a fraction of the SIMULATION cell's reciprocal vectors (SCF is built on the simulation cell,
+    # process.py:87), so that moving one electron by a supercell vector multiplies psi by exp(2 pi i twist) (test_network.py:86-106)
+    kpts = kpts + np.dot(np.linalg.inv(simulation_cell.a), np.mod(np.asarray(twist, dtype=np.float64), 1.0)) * 2 * np.pi
     nk = kpts.shape[0]
-    klist = []
+    occ = []
     for ns in simulation_cell.nelec:
         base, rem = divmod(int(ns), nk)
-        occ = [base + (1 if i < rem else 0) for i in range(nk)]
-        rows = [np.tile(k[None, :], (o, 1)) for k, o in zip(kpts, occ) if o > 0]
+        occ.append([base + (1 if i < rem else 0) for i in range(nk)])
+    return klist_from_occupations(kpts, occ)
+
+
+def klist_from_occupations(kpts, n_occ):
+    """hf.py:99-104: every k-point repeated by the number of orbitals occupied there, per spin.
+    kpts (nk, 3); n_occ [spin][k] integers.  -> [klist_up (n_up, 3), klist_dn (n_dn, 3)]."""
+    kpts = np.asarray(kpts, dtype=np.float64).reshape(-1, 3)
+    klist = []
+    for occ in n_occ:
+        rows = [np.tile(k[None, :], (int(o), 1)) for k, o in zip(kpts, occ) if int(o) > 0]
         klist.append(np.concatenate(rows, axis=0) if rows else np.zeros((0, 3)))
     return klist
+
+
+def klist_from_scf(kpts, mo_occ):
+    """`klist` of a finished PySCF k-point SCF exactly as hf.SCF.init_scf builds it (hf.py:84-104), from plain arrays:
+    `kpts` = kmf.kpts (nk, 3) and `mo_occ` = kmf.mo_occ, either restricted [k][mo] (occupations 0 / 2: spin up counts
+    occupations > 0.9, spin down > 1.1, hf.py:93-95) or unrestricted [spin][k][mo] (> 0.9, hf.py:91).  Ragged per-k lists
+    are accepted."""
+    occ = [np.asarray(o, dtype=np.float64) for o in mo_occ] if not isinstance(mo_occ, np.ndarray) else mo_occ
+    unrestricted = (isinstance(occ, np.ndarray) and occ.ndim == 3) or \
+                   (not isinstance(occ, np.ndarray) and len(occ) == 2 and np.asarray(occ[0], dtype=object).ndim >= 1
+                    and all(np.ndim(o) == 2 or (np.ndim(o) == 1 and np.asarray(o).dtype == object) for o in occ))
+    nk = np.asarray(kpts).reshape(-1, 3).shape[0]
+    if unrestricted:
+        n_occ = [[int(np.sum(np.asarray(occ[s][k]) > 0.9)) for k in range(nk)] for s in range(2)]
+    else:
+        n_occ = [[int(np.sum(np.asarray(occ[k]) > thr)) for k in range(nk)] for thr in (0.9, 1.1)]
+    return klist_from_occupations(kpts, n_occ)
+
+
+def load_hf_klist(path):
+    """`klist` from a saved HF run: an .npz written as ``np.savez(path, kpts=kmf.kpts, mo_occ=np.asarray(kmf.mo_occ))``
+    (restricted: (nk, nmo); unrestricted: (2, nk, nmo)).  PySCF's own chkfile is HDF5, which this image cannot read."""
+    with np.load(path, allow_pickle=True) as f:
+        return klist_from_scf(f['kpts'], f['mo_occ'])

@@ -147,7 +147,7 @@ def stages(params, x, klist, simulation_cell, net_kw):
         phi = torch.complex(o[:, :nparam], o[:, nparam:])               # (ns, nparam, D)
         pi_, sg_ = params['envelope'][ch]['pi'], params['envelope'][ch]['sigma']   # (A, nparam)
         kpts = _t(klist[s])                                              # (ns, 3)
-        M = torch.zeros(ns, nparam, D, dtype=torch.complex128)
+        M = torch.zeros(ns, nparam, D, dtype=onet.cdtype())
         for ii in range(ns):
             i = off + ii
             # envelope e[p] = sum_a pi exp(-|sd sigma|): 5-jet in x_i
@@ -181,9 +181,9 @@ def stages(params, x, klist, simulation_cell, net_kw):
 
     # --- determinants: log D_k, grad, lap  (closed form above) ---------------------------
     K = mats[0].shape[0]
-    logD = torch.zeros(K, dtype=torch.complex128)
-    grad = torch.zeros(K, 3 * N, dtype=torch.complex128)
-    lap = torch.zeros(K, dtype=torch.complex128)
+    logD = torch.zeros(K, dtype=onet.cdtype())
+    grad = torch.zeros(K, 3 * N, dtype=onet.cdtype())
+    lap = torch.zeros(K, dtype=onet.cdtype())
     for M in mats:
         M0 = M[..., 0]
         sign, la = torch.linalg.slogdet(M0)

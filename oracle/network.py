@@ -15,7 +15,29 @@ DT = torch.float64
 CDT = torch.complex128
 
 
-def _t(a, dtype=DT):
+_WORK = {'dt': DT}
+
+
+class working_dtype:
+    """Context manager: run the restatement in another real dtype (float32 for the fp32 error budget of BASELINE config 5:
+    what a straight float32 evaluation of the reference algorithm gives).  Build the network inside the context."""
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.old = _WORK['dt']
+        _WORK['dt'] = self.dtype
+
+    def __exit__(self, *exc):
+        _WORK['dt'] = self.old
+
+
+def cdtype():
+    return torch.complex128 if _WORK['dt'] == torch.float64 else torch.complex64
+
+
+def _t(a, dtype=None):
+    dtype = dtype or _WORK['dt']
     if isinstance(a, torch.Tensor):
         return a.to(dtype)
     return torch.as_tensor(np.asarray(a), dtype=dtype)
@@ -278,7 +300,7 @@ def init_solid_fermi_net_params(rng, atoms, spins, envelope_type='full', bias_or
     return params
 
 
-def params_to_torch(params, dtype=DT):
+def params_to_torch(params, dtype=None):
     def conv(o):
         if isinstance(o, dict):
             return {k: conv(v) for k, v in o.items()}

@@ -286,6 +286,37 @@ def test_float32_chain_vs_float64_oracle(name):
     assert np.abs(ew.cpu().numpy() - fx['ewald'][:nb].sum(-1)).max() < 2e-3 * max(1.0, np.abs(fx['ewald'][:nb].sum(-1)).max())
 
 
+@pytest.mark.parametrize('name', ['lih', 'bcc_li', 'diamond'])
+def test_float32_error_budget(name):
+    """fp32 (BASELINE config 5) error budget: what a straight float32 evaluation of the REFERENCE algorithm loses (the
+    oracle's autodiff `hessian` mode and its forward-Laplacian mode run in float32 on the CPU) next to what the HIP float32
+    chain loses, both against the float64 value at the float32-rounded walker.  The HIP chain must not be worse than 3x the
+    worse of the two float32 restatements (+1e-6 relative floor); the numbers are printed for the record."""
+    from deepsolid_amd import hamiltonian, network
+    fx, cell, klist, net_kw, params = load_case(name)
+    nb = 2
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v]
+          for k, v in params.items()}
+    x32 = torch.as_tensor(fx['x'][:nb], dtype=torch.float32)
+    ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', dtype=torch.float32, **net_kw)
+    ke, _ = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, x32.cuda())
+    p64 = onet.params_to_torch(params)
+    p32 = onet.params_to_torch(params, dtype=torch.float32)
+    e_hip, e_fl, e_ad = [], [], []
+    for b in range(nb):
+        ref = complex(ofl.stages(p64, x32[b].double(), klist, cell, net_kw)['ke'])
+        sc = max(1.0, abs(ref))
+        e_hip.append(abs(complex(ke[b].cpu()) - ref) / sc)
+        with onet.working_dtype(torch.float32):
+            e_fl.append(abs(complex(ofl.stages(p32, x32[b], klist, cell, net_kw)['ke']) - ref) / sc)
+            if b == 0:
+                net32 = oracle_net(cell, klist, net_kw, 'eval_logdet')
+                e_ad.append(abs(complex(sum(oham.local_kinetic_energy_real_imag_hessian(net32.apply)(p32, x32[b]))) - ref) / sc)
+    print(f'{name}: relative E_kin error in float32 -- HIP {max(e_hip):.2e}, forward-Laplacian restatement {max(e_fl):.2e}, '
+          f'autodiff restatement {max(e_ad):.2e}')
+    assert max(e_hip) <= 3 * max(max(e_fl), max(e_ad)) + 1e-6, (e_hip, e_fl, e_ad)
+
+
 @pytest.mark.parametrize('name', OPTION_CASES)
 def test_network_options_local_energy_vs_autodiff_oracle(name):
     """full_det / diagonal and full envelopes / orbital bias / the factory's own defaults

@@ -283,3 +283,28 @@ def test_bench_launcher_spawns_one_rank_per_gpu(scaling, per_gpu):
     assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['scaling'] == scaling
     assert d['config']['batch_per_gpu'] == per_gpu and d['config']['global_batch'] == (4096 if scaling == 'strong' else 8192)
     assert d['max_rank_seconds'] == pytest.approx(2e-3)            # the MAX over ranks, not rank 0's own time
+
+
+def test_klist_from_a_saved_hf_run(tmp_path):
+    """hf.SCF.init_scf (hf.py:84-104) from plain arrays: restricted (occupations 0/2) and unrestricted mo_occ, and the
+    .npz loader; the synthetic make_klist is the same construction with uniform fillings."""
+    from deepsolid_amd import supercell
+    cell, klist = systems.build('bcc_li', twist=(0.3, 0.0, 0.15))
+    kpts = supercell.get_supercell_kpts(cell) + np.dot(np.linalg.inv(cell.a), [0.3, 0.0, 0.15]) * 2 * np.pi
+    nk, nmo = kpts.shape[0], 5
+    occ_r = np.zeros((nk, nmo)); occ_r[:, 0] = 2.0; occ_r[:4, 1] = 2.0            # 8 + 4 doubly occupied orbitals: (12, 12)
+    up, dn = supercell.klist_from_scf(kpts, occ_r)
+    assert up.shape == (12, 3) and dn.shape == (12, 3)
+    np.testing.assert_allclose(up[:2], np.tile(kpts[0], (2, 1)))
+    np.testing.assert_allclose(up, dn)
+    occ_u = np.zeros((2, nk, nmo)); occ_u[0, :, 0] = 1.0; occ_u[0, :4, 1] = 1.0; occ_u[1, :, 0] = 1.0
+    up, dn = supercell.klist_from_scf(kpts, occ_u)
+    assert up.shape == (12, 3) and dn.shape == (8, 3)
+    np.savez(tmp_path / 'hf.npz', kpts=kpts, mo_occ=occ_r)
+    for a, b in zip(supercell.load_hf_klist(tmp_path / 'hf.npz'), supercell.klist_from_scf(kpts, occ_r)):
+        np.testing.assert_array_equal(a, b)
+    # the twist is a fraction of the SIMULATION cell's reciprocal lattice (hf.py:61): one electron moved by a supercell
+    # vector picks up exp(2 pi i twist)
+    for j, t in enumerate((0.3, 0.0, 0.15)):
+        ph = np.exp(1j * klist[0] @ cell.a[j])
+        np.testing.assert_allclose(ph, np.exp(2j * np.pi * t) * np.ones(len(ph)), atol=1e-12)

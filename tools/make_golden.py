@@ -171,7 +171,7 @@ def main():
         sim = ref_supercell(rsc, prim, my_cell.S, my_cell.nelec, case.get('sym_type', 'minimal'))
         kpts = rsc.get_supercell_kpts(sim)
         twist = np.asarray(case.get('twist', (0, 0, 0)), float)
-        kpts_t = kpts + np.dot(np.linalg.inv(prim.a), np.mod(twist, 1.0)) * 2 * np.pi   # hf.py:61-62
+        kpts_t = kpts + np.dot(np.linalg.inv(sim.a), np.mod(twist, 1.0)) * 2 * np.pi    # hf.py:61-62 (cell = the simulation cell)
         klist = klist_from_kpts(kpts_t, sim.nelec)   # grouping shaped like hf.py:99-104
         N = sum(sim.nelec)
         net_kw = dict(systems.DETNET_DEFAULTS); net_kw.update(case.get('net_kw', {}))
