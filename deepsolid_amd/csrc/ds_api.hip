@@ -48,6 +48,7 @@ void inv3(const double* a, double* o) {
 // per-walker workspace carve, in elements
 struct WsLayout {
     size_t G, MEAN, ZB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
+    size_t PARTM = 0;                                      // value chain: per-tile segment sums of the pair layer (k_two_layer)
     size_t mout_off[2], minv_off[2], dets_off[2], tr_off[2];
     size_t per_walker;                                     // total elements per walker
 };
@@ -71,6 +72,7 @@ struct ds_system {
     // optional two-way chunk pipelining (DS_STREAMS=2): bandwidth-bound kernels of one chunk overlap the MFMA-bound
     // kernels of the other; the side streams fork from / join the caller's stream with events
     int n_streams = 1;
+    bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -252,7 +254,8 @@ void build_layouts(ds_system* s) {
     }
     v.MOUT = mo; v.MINV = 0; v.TR = 0;
     v.DETS = w.DETS * PV;             // DETS stays per walker
-    v.per_walker = 2 * v.G + 2 * v.MEAN + v.ZB + 2 * v.H2 + v.Q + v.MOUT + v.DETS;
+    v.PARTM = (size_t)(PV / 5) * h2max * 5 * (S.NP / 16) * ds::PM_SLOTS;
+    v.per_walker = 2 * v.G + 2 * v.MEAN + v.ZB + 2 * v.H2 + v.Q + v.MOUT + v.DETS + v.PARTM;
 }
 
 template <typename T> struct Carve {
@@ -288,7 +291,9 @@ template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
         case 8: f(std::integral_constant<int, 2>(), std::integral_constant<int, 8>()); return 0;
         case 9: f(std::integral_constant<int, 2>(), std::integral_constant<int, 9>()); return 0;
         case 10: f(std::integral_constant<int, 2>(), std::integral_constant<int, 10>()); return 0;
-        case 19: f(std::integral_constant<int, 1>(), std::integral_constant<int, 19>()); return 0;
+        // 96 electrons: 16 features x 304 slots per wave in float64, 32 features in float32 (152 accumulator registers either way;
+        // larger tiles need AGPR accumulators and spill)
+        case 19: f(std::integral_constant<int, (sizeof(T) == 4 ? 2 : 1)>(), std::integral_constant<int, 19>()); return 0;
         default: return 1;
     }
 }
@@ -509,7 +514,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
 template <typename T> struct ValBufs {
     T* Gl[DS_MAX_LAYERS + 1];
     T* H2l[DS_MAX_LAYERS + 1];
-    T *MEAN0, *MEANS, *ZB, *Q, *MOUT, *DETS;     // MEANS: spin means of a hidden layer's input (scratch of k_spin_mean)
+    T *MEAN0, *MEANS, *ZB, *Q, *MOUT, *DETS, *PARTM;     // MEANS: spin means of a hidden layer's input (scratch of k_spin_mean)
     T* PHI[2];              // orbital GEMM output per spin channel (the plain pass reuses ZB for both)
     T* SORB[2];             // use_last_layer: shared term of the orbital head
     T* MINV;                // optional inverses, laid out like MOUT (walker-interleaved)
@@ -529,6 +534,7 @@ ValBufs<T> carve_value(ds_system* s, void* ws, int64_t ng) {
     b.Q = p; p += L.Q * ng;
     b.MOUT = p; p += L.MOUT * ng;
     b.DETS = p; p += L.DETS * ng;
+    b.PARTM = p; p += L.PARTM * ng;
     b.MEAN0 = MEAN[0];
     b.MEANS = MEAN[1];
     for (int l = 0; l <= S.n_layers; ++l) { b.Gl[l] = G[l & 1]; b.H2l[l] = H2[l & 1]; }
@@ -556,19 +562,29 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
     hipLaunchKernelGGL((ds::k_features_val<T, 1>), dim3((unsigned)ng, ds::FV_SPLIT), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
                        blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), vb.Gl[0], vb.MEAN0, vb.H2l[0], Q);
     const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
+    const bool fuse_means = S.n_up >= 8 && (S.n_dn >= 8 || S.n_dn == 0) && !s->no_fuse_means;
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
         T* Gin = vb.Gl[l]; T* Gout = vb.Gl[l + 1];
         // the pair stream stops changing after the last two-electron layer
         T* Hin = vb.H2l[l < S.n_double ? l : S.n_double];
-        hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, Hin, K2, Gin, Kh);
+        // partner means of the pair stream -> rows [Kh, Kh + nch*K2): layer 0 from H2 itself; later layers from the segment sums
+        // the previous pair layer left behind (no second pass over H2) when every spin has >= 8 electrons
+        if (l > 0 && l <= S.n_double && fuse_means)
+            hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng), dim3(256), (size_t)S.nch * K2 * PV * sizeof(T), st, S, vb.PARTM, K2, Gin, Kh);
+        else
+            hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, Hin, K2, Gin, Kh);
         if (l < S.n_double) {
             const int K2o = S.h2[l + 1];
             if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
             dim3 grid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
             const bool res = K2 == K2o;
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
-#define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, true>), grid, dim3(256), 0, st, S, Hin, K2, W2, b2, vb.H2l[l + 1])
+            // the last pair layer's output is only needed as means unless the activations are kept (gradient pass) or the
+            // orbital head / a later layer reads H2 again without a pair layer in between
+            T* Hnext = (fuse_means && !vb.MINV && l + 1 == S.n_double) ? (T*)nullptr : vb.H2l[l + 1];
+            T* pmv = fuse_means ? vb.PARTM : (T*)nullptr;
+#define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, true>), grid, dim3(256), 0, st, S, Hin, K2, W2, b2, Hnext, pmv)
             if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
             else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
 #undef DS_TWO
@@ -599,7 +615,10 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
     }
     T* Gl = vb.Gl[S.n_layers];
     const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
-    if (s->use_last) hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, vb.H2l[S.n_double], K2l, Gl, Kl);
+    if (s->use_last) {
+        if (fuse_means) hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng), dim3(256), (size_t)S.nch * K2l * PV * sizeof(T), st, S, vb.PARTM, K2l, Gl, Kl);
+        else hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, vb.H2l[S.n_double], K2l, Gl, Kl);
+    }
     for (int sp = 0; sp < S.nch; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
         const int Korb = Kl + (s->use_last ? S.nch * K2l : 0);
@@ -790,7 +809,7 @@ int grad_plan(const ds_system* s, GradPlan* gp) {
     gp->w2s = (size_t)(PV / 5) * h2max * h2max;
     gp->sbar = (size_t)std::max(h1max, ocmax) * PV;
     const WsLayout& v = s->wsv;
-    gp->per_group = (size_t)(S.n_layers + 1) * v.G + (size_t)(S.n_double + 1) * gp->h2 + 3 * v.MEAN + v.ZB + 2 * v.Q + 2 * v.MOUT + v.DETS +
+    gp->per_group = (size_t)(S.n_layers + 1) * v.G + (size_t)(S.n_double + 1) * gp->h2 + 3 * v.MEAN + v.ZB + 2 * v.Q + 2 * v.MOUT + v.DETS + v.PARTM +
                     2 * phi + (size_t)S.K * 2 * PV + gp->gbar + 3 * gp->hb + gp->sbar + 3 * gp->h2 + (size_t)s->nparams +
                     gp->w2s + (s->use_last ? v.MEAN + (size_t)S.nch * ocmax * PV : 0);
     return 0;
@@ -850,6 +869,7 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
         vb.MOUT = p; p += V.MOUT * ng;
         vb.MINV = p; p += V.MOUT * ng;
         vb.DETS = p; p += V.DETS * ng;
+        vb.PARTM = p; p += V.PARTM * ng;
         T* PB[2] = {nullptr, nullptr};
         for (int c = 0; c < S.nch; ++c) { vb.PHI[c] = p + gp.phi_off[c] * ng; vb.SORB[c] = nullptr; }
         p += gp.phi_total * ng;
@@ -1085,6 +1105,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     // environment switches are read here, once; the launch paths never call getenv
     if (const char* e = getenv("DS_STREAMS")) s->n_streams = atoi(e) == 2 ? 2 : 1;
     s->det_valu = getenv("DS_DET_VALU") != nullptr;
+    s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     if (s->n_streams == 2) {
         bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < 2 && ok; ++k)

@@ -51,6 +51,23 @@ template <typename T> __device__ __forceinline__ T row16_sum(T v) {
     v += dpp_mov<0x140>(v);
     return v;
 }
+// inclusive prefix sum over the 16 lanes of a row (row_shr:1,2,4,8 with zero fill)
+template <int CTRL> __device__ __forceinline__ double dpp_shr0(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_shr0(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <typename T> __device__ __forceinline__ T row16_prefix(T v) {
+    v += dpp_shr0<0x111>(v);
+    v += dpp_shr0<0x112>(v);
+    v += dpp_shr0<0x114>(v);
+    v += dpp_shr0<0x118>(v);
+    return v;
+}
 // lane L of every row broadcast to its row (row_share:L)
 template <int L, typename T> __device__ __forceinline__ T row16_bcast(T v) { return dpp_mov<0x150 + L>(v); }
 // the same with the lane chosen by a loop index that is a constant after unrolling (N <= 16 cases)

@@ -37,7 +37,7 @@ template <typename T> struct OrbEpi {
 // when two workgroups share a CU (NB >= 3), 64 KB otherwise.
 template <typename T, int NB, int ST> constexpr int stash_blocks() {
     constexpr int waves = (NB == 3 || ST > 10) ? 4 : 16 / NB;
-    constexpr int budget = (NB >= 3 ? 80 : 64) * 1024;
+    constexpr int budget = (ST > 10 ? 150 : (NB >= 3 ? 80 : 64)) * 1024;      // ST > 10: one four-wave workgroup per CU
     constexpr int per_block = waves * 4 * ST * 64 * (int)sizeof(T);
     return budget / per_block > NB ? NB : budget / per_block;
 }
@@ -48,7 +48,7 @@ template <typename T, int NB, int ST> inline size_t gemm_stash_bytes(unsigned th
 // Depth of the operand ring: as many k-steps of operands as the register file leaves next to the accumulators (256 VGPRs per
 // wave with two waves per SIMD, 512 for the four-wave workgroups of the widest tiles), at most four, at least two.
 template <typename T, int NB, int ST> constexpr int ring_sets() {
-    constexpr int vg = (int)sizeof(T) / 4, limit = (NB == 1 || ST > 10) ? 512 : 256;
+    constexpr int vg = (int)sizeof(T) / 4, limit = ST > 10 ? 512 : 256;
     constexpr int n = (limit - NB * ST * 4 * vg - 24) / ((NB + ST) * vg);
     return n > 4 ? 4 : (n < 2 ? 2 : n);
 }
@@ -72,7 +72,7 @@ __host__ __device__ constexpr bool gemm_uses_ring(int epi) { return epi == 0 || 
 //            phase 5-jet of the tile's electron) with the product rule, stored into MOUT.
 template <typename T, int NB, int ST, int EPI>
 // (very wide slot ranges, ST > 10: four waves per workgroup so that a wave may use the whole register file)
-__global__ void __launch_bounds__((NB == 3 || ST > 10 ? 256 : 1024 / NB), (NB >= 3 ? 2 : 1))
+__global__ void __launch_bounds__((NB == 3 || ST > 10 ? 256 : 1024 / NB), (NB >= 3 && ST <= 10 ? 2 : 1))
 k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride, const T* __restrict__ W, int K,
            const T* __restrict__ X2, size_t x2_walker_stride, const T* __restrict__ W2, int K2, int n_tiles,
            T* __restrict__ Z, size_t z_walker_stride, int Nout, int P, const T* __restrict__ Sb,

@@ -246,9 +246,16 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
 //     MFMA, C[n][(c,pair)] ; the five jet components of a pair sit in five accumulator tiles of the
 //     same lane, so the tanh chain rule is lane-local.
 // =====================================================================================
+// (value chain only) PARTM != nullptr: the wave also leaves, per output feature / walker column, the running sums of its 16
+// pairs at the end of every (electron, partner spin) segment -- up to PM_SLOTS segments meet a 16-pair tile when every spin has
+// >= 8 electrons -- in PARTM[w][tile][slot][feature][column] (one 16-lane prefix sum per value, staged in LDS, written as one
+// contiguous block); k_m2_combine_val takes differences and adds the (at most three) tiles of a segment in index order, so the
+// partner means of the NEXT one-electron layer need no second pass over H2 and stay bit-reproducible.  Hout == nullptr:
+// the layer output itself is not needed (last pair layer of a log-psi forward).
+constexpr int PM_SLOTS = 3;
 template <typename T, int NT2, bool RES, bool VAL>
 __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __restrict__ Hin, int Kin, const T* __restrict__ W,
-                                                   const T* __restrict__ bias, T* __restrict__ Hout) {
+                                                   const T* __restrict__ bias, T* __restrict__ Hout, T* __restrict__ PARTM = nullptr) {
     typedef typename Acc4<T>::type acc_t;
     const int w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pt = blockIdx.x * 4 + wave, NP = S.NP, Kout = 16 * NT2;
@@ -267,6 +274,18 @@ __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __re
     }
     const T rs2 = T(0.70710678118654752440);
     T* Ho = Hout + (size_t)w * Kout * 5 * NP + pt * 16 + lr;
+    __shared__ T pm_stage[VAL ? 4 * PM_SLOTS * 16 * NT2 * 5 : 1];
+    T* pm_lds = pm_stage + (VAL ? wave * (PM_SLOTS * Kout * 5) : 0);
+    bool pm_valid = false, pm_last = false;
+    int pm_slot = 0;
+    if (VAL && PARTM) {
+        const int N = S.N, nch = S.nch;
+        auto seg_of = [&](int p) { const int e = p / N, j = p - e * N; return p < N * N ? e * nch + (nch > 1 && j >= S.n_up ? 1 : 0) : -1; };
+        const int p = pt * 16 + lr, sg = seg_of(p);
+        pm_valid = sg >= 0;
+        pm_slot = sg - seg_of(pt * 16);
+        pm_last = pm_valid && (lr == 15 || seg_of(p + 1) != sg);
+    }
     for (int a = 0; a < NT2; ++a)
         for (int r = 0; r < 4; ++r) {
             const int n = 16 * a + acc_row<T>(lane, r);
@@ -280,9 +299,51 @@ __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __re
             for (int c = 0; c < 5; ++c) {
                 T v = o[c];
                 if (RES) v = (Hw[(size_t)(n * 5 + c) * NP] + v) * rs2;
-                Ho[(size_t)(n * 5 + c) * NP] = v;
+                if (Hout) Ho[(size_t)(n * 5 + c) * NP] = v;
+                if (VAL && PARTM) {
+                    // running sum over the tile's pairs; the last lane of every (electron, spin) segment keeps its prefix:
+                    // slot q of the tile holds the sum of segments 0..q (k_m2_combine_val takes differences)
+                    const T pre = row16_prefix(pm_valid ? v : T(0));
+                    if (pm_last) pm_lds[(pm_slot * Kout + n) * 5 + c] = pre;
+                }
             }
         }
+    if (VAL && PARTM) {
+        // PARTM[w][tile][slot][feature][column]: PM_SLOTS * Kout * 5 contiguous values per wave, written coalesced
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        T* pm = PARTM + ((size_t)w * (NP / 16) + pt) * (PM_SLOTS * Kout * 5);
+        for (int i = lane; i < PM_SLOTS * Kout * 5; i += 64) pm[i] = pm_lds[i];
+    }
+}
+
+// rows [row0, row0 + nch*K2) of G (value chain) from the per-tile segment sums of k_two_layer: mean over the partners j of
+// spin s of h2[j][e] = (sum over the tiles that meet segment (e, s), in tile order) / n_s.   grid (N, groups), block 256.
+// Reads walk (feature, column-in-5) fastest -- contiguous in PARTM --, the result is transposed through LDS so that the
+// G rows are written column-contiguous.
+template <typename T>
+__global__ void __launch_bounds__(256) k_m2_combine_val(SysDev<T> S, const T* __restrict__ PARTM, int K2, T* __restrict__ G, int row0) {
+    constexpr int PV_ = 80;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* out = reinterpret_cast<T*>(smem_raw);                      // [nch*K2][PV]
+    const int e = blockIdx.x, g = blockIdx.y, N = S.N, nt = S.NP / 16, nch = S.nch;
+    const size_t blk = (size_t)PM_SLOTS * K2 * 5;
+    for (int idx = threadIdx.x; idx < nch * K2 * PV_; idx += blockDim.x) {
+        const int cc = idx % 5, k = (idx / 5) % K2, w5 = (idx / (5 * K2)) % (PV_ / 5), sp = idx / (PV_ * K2);
+        const int a = e * N + (sp == 0 ? 0 : S.n_up), ns = sp == 0 ? S.n_up : S.n_dn, b = a + ns;      // pairs [a, b)
+        const int seg = e * nch + sp;
+        const T* pw = PARTM + ((size_t)g * (PV_ / 5) + w5) * nt * blk;
+        T v = 0;
+        for (int pt = a / 16; pt <= (b - 1) / 16; ++pt) {
+            const int p0 = pt * 16, e0 = p0 / N, j0 = p0 - e0 * N, seg0 = e0 * nch + (nch > 1 && j0 >= S.n_up ? 1 : 0);
+            const int q = seg - seg0;                       // slots hold running sums over the tile's segments
+            v += pw[(size_t)pt * blk + ((size_t)q * K2 + k) * 5 + cc] - (q > 0 ? pw[(size_t)pt * blk + ((size_t)(q - 1) * K2 + k) * 5 + cc] : T(0));
+        }
+        out[(sp * K2 + k) * PV_ + w5 * 5 + cc] = v / T(ns);
+    }
+    __syncthreads();
+    T* Ge = G + ((size_t)(g * N + e) * S.ldk + row0) * PV_;
+    for (int idx = threadIdx.x; idx < nch * K2 * PV_; idx += blockDim.x) Ge[idx] = out[idx];
 }
 
 // (3. one-electron stream layer and 4. orbital head: ds_gemm.h)

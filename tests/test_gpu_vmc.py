@@ -190,6 +190,28 @@ def test_gradient_one_electron_and_importance_moves_vs_oracle(name):
     assert xb.shape == (B, n3) and 0.0 <= float(pb) <= 1.0
 
 
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'bcc_li'])
+def test_other_samplers_vs_reference_vectors(name):
+    """One-electron moves (qmc.py:227-287; N moves through make_mcmc_step) and the drift-biased importance move
+    (qmc.py:83-124) replaying the noise the REFERENCE's own functions consumed (tools/make_golden.py: mh1_*, imp_*)."""
+    from deepsolid_amd import qmc
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    (slog,) = nets(cell, klist, net_kw, 'eval_slogdet')
+    cu = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device='cuda')
+    B = fx['mcmc_x0'].shape[0]
+    s1 = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=1, one_electron_moves=True)
+    xo, pm = s1(dp, cu(fx['mcmc_x0']), (cu(fx['mh1_normals']), cu(fx['mh1_uniforms'])), float(fx['mh1_width']))
+    np.testing.assert_allclose(xo.cpu().numpy(), fx['mh1_x_out'], atol=1e-10)
+    assert abs(float(pm) - float(fx['mh1_pmove'])) < 1e-15
+    nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    xi, _, lpi, nacc = qmc.importance_update(dp, slog.apply.value_and_grad, cu(fx['mcmc_x0']), None, cu(fx['imp_lp1']), nacc, cell.a,
+                                             stddev=float(fx['imp_width']), normal=cu(fx['imp_normal']), uniform=cu(fx['imp_uniform']))
+    np.testing.assert_allclose(xi.cpu().numpy(), fx['imp_x_new'], atol=1e-9)
+    np.testing.assert_allclose(lpi.cpu().numpy(), fx['imp_lp_new'], atol=1e-7)
+    assert float(nacc) == float(fx['imp_num_accepts'])
+
+
 def test_inference_loop_writes_reference_csv(tmp_path):
     """optimizer='none' loop of process.py:289-374 on LiH: CSV schema, width adaptation, finite energies."""
     from deepsolid_amd import inference, init_guess

@@ -275,3 +275,33 @@ def test_energy_gradient_matches_reference_train(name):
         assert abs(float(aux.variance) - float(fx['grad_ref_variance' + sfx])) < 1e-8 * max(1.0, float(aux.variance))
         assert abs(float(aux.imaginary) - float(fx['grad_ref_imag' + sfx])) < 1e-9
         check_gradient_against_reference(fx, params, g, sfx)
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'bcc_li'])
+def test_other_samplers_match_reference(name):
+    """The reference's own mh_one_electron_update (qmc.py:227-287, N moves through make_mcmc_step) and importance_update
+    (qmc.py:83-124, with the value and gradient of its own network) replayed on the noise they consumed."""
+    from torch.func import grad as tgrad
+    fx, cell, klist, net_kw, params = load_case(name)
+    if 'mh1_x_out' not in fx:
+        pytest.skip('fixture predates the sampler records')
+    p = onet.params_to_torch(params)
+    net = oracle_net(cell, klist, net_kw, 'eval_slogdet')
+    f = lambda pp, xs: torch.stack([net.apply(pp, x) for x in xs])
+    x = tt(fx['mcmc_x0'])
+    lp = 2.0 * f(p, x)
+    nacc = 0.0
+    n = x.shape[1] // 3
+    for i in range(n):                                     # nsteps = N * steps, electron i % N (qmc.py:355-356)
+        x, lp, nacc = oqmc.mh_one_electron_update(p, f, x, lp, nacc, cell.a, stddev=float(fx['mh1_width']), i=i,
+                                                  normal=tt(fx['mh1_normals'][i]), uniform=tt(fx['mh1_uniforms'][i]))
+    np.testing.assert_allclose(x.numpy(), fx['mh1_x_out'], atol=1e-11)
+    assert abs(float(nacc) / (n * x.shape[0]) - float(fx['mh1_pmove'])) < 1e-15
+    fg = lambda pp, xs: (f(pp, xs), torch.stack([tgrad(lambda y: net.apply(pp, y))(xx) for xx in xs]))
+    x0 = tt(fx['mcmc_x0'])
+    np.testing.assert_allclose((2.0 * f(p, x0)).numpy(), fx['imp_lp1'], atol=1e-9)
+    xi, lpi, na = oqmc.importance_update(p, fg, x0, tt(fx['imp_lp1']), 0.0, cell.a, stddev=float(fx['imp_width']),
+                                         normal=tt(fx['imp_normal']), uniform=tt(fx['imp_uniform']))
+    np.testing.assert_allclose(xi.numpy(), fx['imp_x_new'], atol=1e-10)
+    np.testing.assert_allclose(lpi.numpy(), fx['imp_lp_new'], atol=1e-8)
+    assert float(na) == float(fx['imp_num_accepts'])

@@ -174,6 +174,8 @@ def _make_jnp():
     dispatch('median', lambda a: _np_median(_t(a)))
     dispatch('allclose', lambda a, b, rtol=1e-5, atol=1e-8: torch.allclose(_t(a), _t(b), rtol=rtol, atol=atol))
 
+    jnp.where = lambda *a: (torch.where(*[_t(v) for v in a]) if _has_tensor(a) else np.where(*a).view(AtArray))
+
     def _split(a, idx, axis=0):
         a = _t(a)
         if isinstance(idx, int):
@@ -320,6 +322,27 @@ def value_and_grad(f, argnums=0, has_aux=False):
         g, v = tf.grad_and_value(f, argnums=argnums)(*args)
         return v, g
     return vg
+
+
+class AtArray(np.ndarray):
+    """numpy array with the `x.at[idx].add(v)` update of jax arrays (qmc.py:269); views and reshapes keep the type."""
+    class _At:
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __getitem__(self, idx):
+            arr = self.arr
+
+            class _Upd:
+                def add(self, v):
+                    out = np.array(arr, copy=True)
+                    out[idx] += v
+                    return out.view(AtArray)
+            return _Upd()
+
+    @property
+    def at(self):
+        return AtArray._At(self)
 
 
 class Recorder:

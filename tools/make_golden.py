@@ -246,6 +246,37 @@ def main():
                      mcmc_x_out=xs3, mcmc_pmove=float(pmove))
 
 
+        # --- the reference's other samplers (flagged "untested" in base_config.py:122-126), replayable noise ----------
+        if case.get('mcmc', True) and case.get('samplers', True):
+            import torch
+            # one-electron moves (qmc.py:227-287) through make_mcmc_step: N moves, electron i = step % N (:355-356)
+            RECORDER.reset(case['seed'] + 700)
+            step1 = rqmc.make_mcmc_step(f_batch, B, sim.a, steps=1, one_electron_moves=True)
+            x1e, pm1 = step1(pnp, wx.view(standin.AtArray), None, 0.3)
+            d.update(mh1_normals=np.asarray(RECORDER.normals).reshape(N, B, 3), mh1_uniforms=np.asarray(RECORDER.uniforms),
+                     mh1_width=0.3, mh1_x_out=np.asarray(x1e), mh1_pmove=float(pm1))
+            # drift-biased importance sampling (qmc.py:83-124): f = value and gradient of log|psi| from the reference network
+            tcell_p = TorchCell(prim); tcell = TorchCell(sim, original=tcell_p)
+            with standin.torch_mode():
+                tnet_s = rnet.make_solid_fermi_net(klist=[torch.as_tensor(k) for k in klist], simulation_cell=tcell,
+                                                   method_name='eval_slogdet', **net_kw)
+            tpar = to_torch_params(pnp)
+
+            def f_vg(p_, xs):
+                vals, grads = [], []
+                with standin.torch_mode():
+                    for xx in np.asarray(xs):
+                        xt = torch.as_tensor(xx).clone().requires_grad_(True)
+                        v = tnet_s.apply(tpar, xt)
+                        g, = torch.autograd.grad(v, xt)
+                        vals.append(float(v)); grads.append(g.numpy())
+                return np.asarray(vals), np.asarray(grads)
+            RECORDER.reset(case['seed'] + 800)
+            lpi = 2.0 * f_vg(pnp, wx)[0]
+            xi, _, lpin, nacci = rqmc.importance_update(pnp, f_vg, wx, None, lpi, 0.0, sim.a, stddev=0.2)
+            d.update(imp_lp1=lpi, imp_normal=RECORDER.normals[0], imp_uniform=RECORDER.uniforms[0], imp_width=0.2,
+                     imp_x_new=np.asarray(xi), imp_lp_new=np.asarray(lpin), imp_num_accepts=float(nacci))
+
         # --- kinetic energy: the reference's OWN hamiltonian.py over its own network.py -----
         # (torch-backed jax stand-in: jax.grad/jvp/hessian -> torch.func, float64)
         nke = case.get('ke_walkers', 0)
