@@ -54,6 +54,8 @@ SIGNATURES = {
     'ds_enforce_pbc': (C.c_int, [_PD, C.c_int, _VP, C.c_int64, _VP, _VP, _VP]),
     'ds_mh_propose': (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, _VP, _VP]),
     'ds_mh_accept': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _VP, _VP]),
+    'ds_mh_propose_ex': (C.c_int, [_VP, C.c_int, _VP, _VP, C.c_double, _VP, C.c_int, C.c_int64, _VP, _VP, _VP]),
+    'ds_mh_accept_ex': (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, C.c_double, _VP, _VP, C.c_int, C.c_int64, _VP, _VP, _VP]),
     'ds_mcmc_workspace_bytes': (C.c_int64, [_VP, C.c_int64]),
     'ds_mcmc_step': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int, C.c_double, C.c_uint64, C.c_uint64, _VP, _VP, C.c_int, _VP, _VP,
                               C.c_int64, _VP]),

@@ -1274,6 +1274,52 @@ int ds_mh_accept(ds_system* s, void* x1, void* lp1, const void* x2, const void* 
     return 0;
 }
 
+int ds_mh_propose_ex(ds_system* s, int mode, const void* x1, const void* normal, double width, const void* aux, int n_aux, int64_t B,
+                     void* x2, void* scratch, void* stream) {
+    if (!s || !x1 || !normal || !aux || !x2) return fail("null argument");
+    if (mode == 2 && !scratch) return fail("the drift move needs a 2-element device scratch (batch maxima of the drift)");
+    if (mode != 1 && mode != 2) return fail("mode must be 1 (asymmetric) or 2 (drift)");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ne = (size_t)B * s->sd.N;
+    dim3 grid((unsigned)((ne + 255) / 256)), block(256);
+    if (s->dtype == 0) {
+        if (mode == 2) hipLaunchKernelGGL((ds::k_max_norm3<double>), dim3(1), dim3(1024), 0, st, (const double*)aux, ne, (double*)scratch);
+        hipLaunchKernelGGL((ds::k_mh_propose_ex<double>), grid, block, 0, st, s->sd.sim_a, s->sd.sim_ainv, mode, (const double*)x1,
+                           (const double*)normal, width, (const double*)aux, n_aux, ne, (double*)x2, (const double*)scratch);
+    } else {
+        if (mode == 2) hipLaunchKernelGGL((ds::k_max_norm3<float>), dim3(1), dim3(1024), 0, st, (const float*)aux, ne, (float*)scratch);
+        hipLaunchKernelGGL((ds::k_mh_propose_ex<float>), grid, block, 0, st, s->sf.sim_a, s->sf.sim_ainv, mode, (const float*)x1,
+                           (const float*)normal, (float)width, (const float*)aux, n_aux, ne, (float*)x2, (const float*)scratch);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int ds_mh_accept_ex(ds_system* s, int mode, void* x1, void* lp1, const void* x2, const void* logabs2, const void* uniform,
+                    const void* normal, double width, const void* aux1, const void* aux2, int n_aux, int64_t B, void* n_accept,
+                    void* scratch, void* stream) {
+    if (!s || !x1 || !lp1 || !x2 || !logabs2 || !uniform || !aux1 || !n_accept) return fail("null argument");
+    if (mode != 1 && mode != 2) return fail("mode must be 1 (asymmetric) or 2 (drift)");
+    if (mode == 2 && (!aux2 || !normal || !scratch)) return fail("the drift move needs both gradients, the normal deviates and the scratch of ds_mh_propose_ex");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t ne = (size_t)B * s->sd.N;
+    if (s->dtype == 0) {
+        if (mode == 2) hipLaunchKernelGGL((ds::k_max_norm3<double>), dim3(1), dim3(1024), 0, st, (const double*)aux2, ne, (double*)scratch + 1);
+        hipLaunchKernelGGL((ds::k_mh_accept_ex<double>), dim3((unsigned)B), dim3(64), 0, st, mode, (double*)x1, (double*)lp1, (const double*)x2,
+                           (const double*)logabs2, (const double*)uniform, (const double*)normal, width, (const double*)aux1,
+                           (const double*)aux2, n_aux, s->sd.N, (double*)n_accept, (const double*)scratch);
+    } else {
+        if (mode == 2) hipLaunchKernelGGL((ds::k_max_norm3<float>), dim3(1), dim3(1024), 0, st, (const float*)aux2, ne, (float*)scratch + 1);
+        hipLaunchKernelGGL((ds::k_mh_accept_ex<float>), dim3((unsigned)B), dim3(64), 0, st, mode, (float*)x1, (float*)lp1, (const float*)x2,
+                           (const float*)logabs2, (const float*)uniform, (const float*)normal, (float)width, (const float*)aux1,
+                           (const float*)aux2, n_aux, s->sf.N, (float*)n_accept, (const float*)scratch);
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int64_t ds_mcmc_workspace_bytes(const ds_system* s, int64_t B) {
     if (!s) return -1;
     return ds_workspace_bytes(s, B) + (int64_t)mcmc_scratch_bytes(s, std::max<int64_t>(B, 1));

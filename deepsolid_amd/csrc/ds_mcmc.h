@@ -105,6 +105,111 @@ __global__ void k_mcmc_accept(T* __restrict__ x1, T* __restrict__ lp1, const T* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's other proposals (flagged "untested", base_config.py:122-126), per move, noise supplied by the caller:
+//   mode 1  asymmetric all-electron move (qmc.py:197-215): step width scaled per electron by the harmonic mean of its
+//           (non-periodic) distances to the nuclei `aux1` (A,3); forward / reverse proposal densities in the test
+//   mode 2  drift-biased importance move (qmc.py:83-124): x2 = x1 + w N + w^2 limdrift(grad log|psi|), aux1 / aux2 =
+//           gradients (B,3N) at x1 / x2.  limdrift (qmc.py:63-81) divides g by clip(|g|, cutoff, max over the batch):
+//           k_max_norm3 supplies the batch maximum (it is the binding bound when every drift is below the cutoff).
+template <typename T> __device__ __forceinline__ T harmonic_mean_dist(const T x[3], const T* __restrict__ atoms, int n_atoms) {
+    T s = 0;
+    for (int a = 0; a < n_atoms; ++a) {
+        const T dx = x[0] - atoms[3 * a], dy = x[1] - atoms[3 * a + 1], dz = x[2] - atoms[3 * a + 2];
+        s += T(1) / ds_sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    return T(1) / (s / T(n_atoms));                          // qmc.py:58-60
+}
+
+// cutoff / clip(|g|, a_min = cutoff, a_max = gmax) with numpy's clip = min(max(x, a_min), a_max): when every drift of the
+// batch is below the cutoff the upper bound (the batch maximum, qmc.py:78) wins and all drifts are scaled by 1 / gmax
+template <typename T> __device__ __forceinline__ T limdrift_factor(const T g[3], T gmax) {
+    const T tot = ds_sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    const T lo = tot > T(1) ? tot : T(1);                    // cutoff = 1
+    return T(1) / (lo < gmax ? lo : gmax);
+}
+
+// out[0] = max over the n_elec electrons of |g_e| (one workgroup; the maximum does not depend on the order)
+template <typename T>
+__global__ void __launch_bounds__(1024) k_max_norm3(const T* __restrict__ g, size_t n_elec, T* __restrict__ out) {
+    __shared__ T sh[1024];
+    T m = 0;
+    for (size_t e = threadIdx.x; e < n_elec; e += 1024) {
+        const T t = ds_sqrt(g[3 * e] * g[3 * e] + g[3 * e + 1] * g[3 * e + 1] + g[3 * e + 2] * g[3 * e + 2]);
+        m = t > m ? t : m;
+    }
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) sh[threadIdx.x] = sh[threadIdx.x + s2] > sh[threadIdx.x] ? sh[threadIdx.x + s2] : sh[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+template <typename T>
+__global__ void k_mh_propose_ex(const T* __restrict__ a, const T* __restrict__ ainv, int mode, const T* __restrict__ x1,
+                                const T* __restrict__ normal, T width, const T* __restrict__ aux, int n_aux, size_t n_elec,
+                                T* __restrict__ x2, const T* __restrict__ gmax) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_elec) return;
+    T p[3], r[3], o[3], wr[3];
+    for (int c = 0; c < 3; ++c) p[c] = x1[3 * e + c];
+    if (mode == 1) {
+        const T sc = width * harmonic_mean_dist(p, aux, n_aux);                      // qmc.py:200-203
+        for (int c = 0; c < 3; ++c) r[c] = p[c] + sc * normal[3 * e + c];
+    } else {
+        T g[3] = {aux[3 * e], aux[3 * e + 1], aux[3 * e + 2]};
+        const T f = limdrift_factor(g, gmax[0]);
+        for (int c = 0; c < 3; ++c) r[c] = p[c] + width * normal[3 * e + c] + width * width * f * g[c];   // qmc.py:112-114
+    }
+    wrap_point(r, a, ainv, o, wr);
+    for (int c = 0; c < 3; ++c) x2[3 * e + c] = o[c];
+}
+
+// one 64-lane workgroup per walker
+template <typename T>
+__global__ void __launch_bounds__(64) k_mh_accept_ex(int mode, T* __restrict__ x1, T* __restrict__ lp1, const T* __restrict__ x2,
+                                                     const T* __restrict__ logabs2, const T* __restrict__ uniform,
+                                                     const T* __restrict__ normal, T width, const T* __restrict__ aux1,
+                                                     const T* __restrict__ aux2, int n_aux, int n_elec, T* __restrict__ n_accept,
+                                                     const T* __restrict__ gmax) {
+    const long w = blockIdx.x;
+    const int n3 = 3 * n_elec;
+    T acc = 0;
+    for (int e = threadIdx.x; e < n_elec; e += 64) {
+        const size_t o = (size_t)w * n3 + 3 * e;
+        if (mode == 1) {
+            T p1[3] = {x1[o], x1[o + 1], x1[o + 2]}, p2[3] = {x2[o], x2[o + 1], x2[o + 2]};
+            const T s1 = width * harmonic_mean_dist(p1, aux1, n_aux), s2 = width * harmonic_mean_dist(p2, aux1, n_aux);
+            T d2 = 0;
+            for (int c = 0; c < 3; ++c) d2 += (p1[c] - p2[c]) * (p1[c] - p2[c]);
+            // lq_2 - lq_1, _log_prob_gaussian (qmc.py:26-42): -d^2/2 sigma^2 - 3 log sigma, reverse minus forward
+            acc += (T(-0.5) * d2 / (s2 * s2) - 3 * ds_log(s2)) - (T(-0.5) * d2 / (s1 * s1) - 3 * ds_log(s1));
+        } else {
+            T g1[3] = {aux1[o], aux1[o + 1], aux1[o + 2]}, g2[3] = {aux2[o], aux2[o + 1], aux2[o + 2]};
+            const T f1 = limdrift_factor(g1, gmax[0]), f2 = limdrift_factor(g2, gmax[1]);
+            for (int c = 0; c < 3; ++c) {
+                const T ga = width * normal[o + c], bk = ga + width * width * (f1 * g1[c] + f2 * g2[c]);
+                acc += ga * ga - bk * bk;                                            // forward - backward, qmc.py:119-122
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    T lp2 = 2 * logabs2[w];
+    T ratio;
+    if (mode == 1) ratio = lp2 + acc - lp1[w];                                      // qmc.py:212
+    else { lp2 += acc / (2 * width * width); ratio = lp2 - lp1[w]; }                // qmc.py:123-126
+    const bool cond = ratio > ds_log(uniform[w]);
+    if (cond)
+        for (int c = threadIdx.x; c < n3; c += 64) x1[(size_t)w * n3 + c] = x2[(size_t)w * n3 + c];
+    __syncthreads();
+    if (threadIdx.x == 0 && cond) {
+        lp1[w] = lp2;
+        atomicAdd(n_accept, T(1));
+    }
+}
+
 template <typename T> __global__ void k_scale2(const T* __restrict__ in, long n, T* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = 2 * in[i];

@@ -453,6 +453,26 @@ class DeviceSystem:
         _lib.check(self.lib.ds_mh_accept(self.handle, _ptr(x1), _ptr(lp1), _ptr(x2), _ptr(lp2), _ptr(uniform),
                                          x1.shape[0], _ptr(n_accept), _stream()), 'ds_mh_accept')
 
+    def mh_propose_ex(self, mode, x1, normal, width, aux, scratch=None):
+        """`ds_mh_propose_ex`: mode 1 asymmetric (aux = nuclei (A,3)), mode 2 drift (aux = grad log|psi| (B,3N))."""
+        x1 = self._check_x(x1)
+        normal = self._check_x(normal)
+        aux = aux.to(device=self.device, dtype=self.dtype).contiguous()
+        x2 = torch.empty_like(x1)
+        n_aux = aux.shape[0] if mode == 1 else 0
+        _lib.check(self.lib.ds_mh_propose_ex(self.handle, int(mode), _ptr(x1), _ptr(normal), float(width), _ptr(aux), int(n_aux),
+                                             x1.shape[0], _ptr(x2), _ptr(scratch), _stream()), 'ds_mh_propose_ex')
+        return x2
+
+    def mh_accept_ex(self, mode, x1, lp1, x2, logabs2, uniform, normal, width, aux1, aux2, n_accept, scratch=None):
+        """`ds_mh_accept_ex`: in-place select on x1 / lp1; n_accept (1,) is incremented."""
+        cv = lambda t: None if t is None else t.to(device=self.device, dtype=self.dtype).contiguous()
+        aux1, aux2, normal = cv(aux1), cv(aux2), cv(normal)
+        n_aux = aux1.shape[0] if mode == 1 else 0
+        _lib.check(self.lib.ds_mh_accept_ex(self.handle, int(mode), _ptr(x1), _ptr(lp1), _ptr(x2), _ptr(cv(logabs2)), _ptr(cv(uniform)),
+                                            _ptr(normal), float(width), _ptr(aux1), _ptr(aux2), int(n_aux), x1.shape[0],
+                                            _ptr(n_accept), _ptr(scratch), _stream()), 'ds_mh_accept_ex')
+
     def mcmc_step(self, params, x, lp, steps, width, seed=0, offset=0, normals=None, uniforms=None, lp_valid=False,
                   n_accept=None):
         """`ds_mcmc_step`: `steps` all-electron Metropolis moves on x (B,3N) / lp (B,) IN PLACE, enqueued without a host

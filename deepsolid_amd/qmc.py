@@ -73,25 +73,16 @@ def _log_prob_gaussian(x, mu, sigma):
 
 def _mh_update_asymmetric(params, f, x1, key, lp_1, num_accepts, latvec, stddev, atoms, normal, uniform):
     """qmc.py:197-215: proposal width scaled per electron by the harmonic mean of its nuclear distances, with the
-    forward / reverse proposal densities in the acceptance ratio.  The wavefunction and the wrap run in the HIP
-    chain; the per-electron scale factors are a few element-wise tensor operations on the device."""
+    forward / reverse proposal densities in the acceptance ratio: `ds_mh_propose_ex` / `ds_mh_accept_ex` (mode 1) around
+    the value-chain forward."""
     system = f.system
+    _check_latvec(latvec, system)
     atoms = torch.as_tensor(atoms, dtype=x1.dtype, device=x1.device).reshape(-1, 3)
-    n = x1.shape[0]
     normal, uniform = _noise(key, x1, lp_1, normal, uniform)
-    x1r = x1.reshape(n, -1, 1, 3)
-    hmean1 = _harmonic_mean(x1r, atoms)                                          # :200
-    x2 = (x1r + stddev * hmean1 * normal.reshape(x1r.shape)).reshape(n, -1)      # :202-203
-    x2, _ = distance.enforce_pbc(latvec if latvec is not None else system.cell.a, x2.contiguous())   # :204
-    lp_2 = 2.0 * f(params, x2)                                                   # :205
-    x2r = x2.reshape(n, -1, 1, 3)
-    hmean2 = _harmonic_mean(x2r, atoms)                                          # :208
-    lq_1 = _log_prob_gaussian(x1r, x2r, stddev * hmean1)                         # :210
-    lq_2 = _log_prob_gaussian(x2r, x1r, stddev * hmean2)                         # :211
-    cond = (lp_2 + lq_2 - lp_1 - lq_1) > torch.log(uniform)                      # :212, :218-219
-    x_new = torch.where(cond[:, None], x2, x1)
-    lp_new = torch.where(cond, lp_2, lp_1)
-    num_accepts += cond.sum().to(num_accepts.dtype)
+    x2 = system.mh_propose_ex(1, x1, normal.reshape(x1.shape), stddev, atoms)     # :200-204
+    la2 = f(params, x2)                                                           # :205 (lp_2 = 2 f)
+    x_new, lp_new = x1.clone(), lp_1.clone()
+    system.mh_accept_ex(1, x_new, lp_new, x2, la2, uniform, None, stddev, atoms, None, num_accepts)   # :208-222
     return x_new, key, lp_new, num_accepts
 
 
@@ -134,23 +125,21 @@ def mh_one_electron_update(params, f, x1, key, lp_1, num_accepts, latvec=None, s
 def importance_update(params, f, x1, key, lp_1, num_accepts, latvec, stddev=0.02, atoms=None, i=0,
                       normal=None, uniform=None):
     """Drift-biased all-electron move (qmc.py:83-150, symmetric branch).  `f(params, x)` must
-    return (log|psi|, grad log|psi|): ``NetworkApply.value_and_grad``."""
+    return (log|psi|, grad log|psi|): ``NetworkApply.value_and_grad``.  The drift limiter, the proposal, the
+    forward / backward densities and the selection run in `ds_mh_propose_ex` / `ds_mh_accept_ex` (mode 2)."""
     del i
     if atoms is not None:
         raise NotImplementedError('asymmetric importance sampling is not implemented')
     system = f.__self__.system if hasattr(f, '__self__') else f.system
+    _check_latvec(latvec, system)
     normal, uniform = _noise(key, x1, lp_1, normal, uniform)
     _, grad = f(params, x1)                                                       # :111
-    grad = limdrift(grad)
-    gauss = stddev * normal
-    x2, _ = distance.enforce_pbc(latvec if latvec is not None else system.cell.a, x1 + gauss + stddev ** 2 * grad)   # :114-115
+    grad = grad.contiguous()
+    scratch = torch.empty(2, dtype=x1.dtype, device=x1.device)                    # batch maxima of |grad| for limdrift's clip (:78)
+    x2 = system.mh_propose_ex(2, x1, normal, stddev, grad, scratch)               # :112-115
     lpsi_2, new_grad = f(params, x2)                                              # :118
-    new_grad = limdrift(new_grad)
-    forward = (gauss ** 2).sum(-1)
-    backward = ((gauss + stddev ** 2 * (grad + new_grad)) ** 2).sum(-1)
-    lp_2 = 2 * lpsi_2 + 1 / (2 * stddev ** 2) * (forward - backward)              # :119-124
     x_new, lp_new = x1.clone(), lp_1.clone()
-    system.mh_accept(x_new, lp_new, x2.contiguous(), lp_2.contiguous(), uniform.contiguous(), num_accepts)
+    system.mh_accept_ex(2, x_new, lp_new, x2, lpsi_2, uniform, normal, stddev, grad, new_grad.contiguous(), num_accepts, scratch)   # :119-137
     return x_new, key, lp_new, num_accepts
 
 

@@ -173,6 +173,23 @@ int ds_mh_propose(ds_system* sys, const void* x1, const void* normal, double wid
 int ds_mh_accept(ds_system* sys, void* x1, void* lp1, const void* x2, const void* lp2,
                  const void* uniform, int64_t B, void* n_accept, void* stream);
 
+/* The reference's other proposals around the network call, per move, with caller-supplied noise (both are flagged "untested" in
+ * base_config.py:122-126):
+ *   mode 1: asymmetric all-electron move of qmc.mh_update with `atoms` (qmc.py:197-215): x2 = wrap(x1 + width * hmean(x1) * normal),
+ *           hmean = harmonic mean of an electron's non-periodic distances to the nuclei aux (n_aux, 3) (qmc.py:44-60); the test adds
+ *           the reverse / forward proposal densities (_log_prob_gaussian, qmc.py:26-42);
+ *   mode 2: drift-biased move of qmc.importance_update (qmc.py:83-124): x2 = wrap(x1 + width * normal + width^2 * limdrift(grad)),
+ *           aux / aux1 = grad log|psi| at x1 (B,3N), aux2 = the same at x2 (both from ds_logpsi_grad); lp <- 2 log|psi(x2)| +
+ *           (|gauss|^2 - |gauss + width^2 (limdrift g1 + limdrift g2)|^2) / (2 width^2).
+ *           `scratch`: 2 device elements shared by the two calls of one move -- the batch maxima of |grad| that limdrift's clip
+ *           uses as its upper bound (qmc.py:78; it binds only when every drift of the batch is below the cutoff).
+ * ds_mh_accept_ex takes log|psi(x2)| (B,), selects x1 / lp1 in place and increments n_accept. */
+int ds_mh_propose_ex(ds_system* sys, int mode, const void* x1, const void* normal, double width, const void* aux, int n_aux,
+                     int64_t B, void* x2, void* scratch, void* stream);
+int ds_mh_accept_ex(ds_system* sys, int mode, void* x1, void* lp1, const void* x2, const void* logabs2, const void* uniform,
+                    const void* normal, double width, const void* aux1, const void* aux2, int n_aux, int64_t B,
+                    void* n_accept, void* scratch, void* stream);
+
 /* qmc.make_mcmc_step's jitted loop (qmc.py:335-362) for the default sampler (all-electron symmetric mh_update,
  * qmc.py:153-196,217-222): `steps` moves enqueued back to back on `stream`, no host synchronisation:
  *     [lp = 2 log|psi(x)|  if !lp_valid (:357)]
