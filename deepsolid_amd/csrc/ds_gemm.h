@@ -34,10 +34,10 @@ template <typename T> struct OrbEpi {
 // its B operand, and the lane that needs X[n][slot] in the epilogue is a lane that held it in its operand registers at
 // k-step n / 4.  The first stash_blocks() 16-row blocks are parked in LDS on the way (one ds_write per operand, no extra
 // global traffic); only the remaining blocks are re-read from memory in the epilogue.  Budget: half of the CU's 160 KB
-// when two workgroups share a CU (NB >= 3), 64 KB otherwise.
+// when two workgroups share a CU (NB >= 3, ST <= 10), all of it otherwise.
 template <typename T, int NB, int ST> constexpr int stash_blocks() {
     constexpr int waves = (NB == 3 || ST > 10) ? 4 : 16 / NB;
-    constexpr int budget = (ST > 10 ? 150 : (NB >= 3 ? 80 : 64)) * 1024;      // ST > 10: one four-wave workgroup per CU
+    constexpr int budget = (NB >= 3 && ST <= 10 ? 80 : 160) * 1024;           // one workgroup per CU unless NB >= 3, ST <= 10 (two)
     constexpr int per_block = waves * 4 * ST * 64 * (int)sizeof(T);
     return budget / per_block > NB ? NB : budget / per_block;
 }
