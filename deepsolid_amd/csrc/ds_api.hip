@@ -73,6 +73,7 @@ struct ds_system {
     // kernels of the other; the side streams fork from / join the caller's stream with events
     int n_streams = 1;
     bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
+    bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -486,7 +487,14 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
 #define DS_TRM(NTV, SWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV>), dim3(S.K, (unsigned)Bc), dim3(256), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp])
-            if (sw8) { if (nt <= 4) DS_TRM(4, 8); else DS_TRM(6, 8); }
+            if (sw8 && (n == 32 || n == 48) && !s->det_half_slots) {
+                // row-split mode: half the rows of a full slot tile in LDS, nothing computed twice
+                const size_t sbytes = (size_t)(n / 2) * 2 * n * 16 * sizeof(T) + 256 * sizeof(ds::Cx<T>);
+#define DS_TRS(NTV) hipLaunchKernelGGL((ds::k_det_trace_mfma_split<T, NTV>), dim3(S.K, (unsigned)Bc), dim3(256), sbytes, st, S, c.MOUT, L.MOUT,  \
+                                       L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS, L.dets_off[sp])
+                if (n == 32) DS_TRS(4); else DS_TRS(6);        // 2n = 16 NT exactly
+#undef DS_TRS
+            } else if (sw8) { if (nt <= 4) DS_TRM(4, 8); else DS_TRM(6, 8); }
             else if (nt == 1) DS_TRM(1, 16); else if (nt == 2) DS_TRM(2, 16); else if (nt == 3) DS_TRM(3, 16); else if (nt == 4) DS_TRM(4, 16);
             else DS_TRM(6, 16);
 #undef DS_TRM
@@ -1105,6 +1113,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     // environment switches are read here, once; the launch paths never call getenv
     if (const char* e = getenv("DS_STREAMS")) s->n_streams = atoi(e) == 2 ? 2 : 1;
     s->det_valu = getenv("DS_DET_VALU") != nullptr;
+    s->det_half_slots = getenv("DS_DET_HALF_SLOTS") != nullptr;
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     if (s->n_streams == 2) {
         bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;

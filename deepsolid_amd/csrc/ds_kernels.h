@@ -645,6 +645,133 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
 }
 
 // =====================================================================================
+// 5b''. the same for matrices whose 16-slot tile of Y does not fit the LDS (n = 32 in float64, n = 48 in float32), without
+//     computing anything twice: the rows are split in halves I1 | I2 and the columns in C1 | C2 (n a multiple of 16):
+//       pass A  rows I1, all columns           -> sum over (i, e) in I1 x I1 and the diagonal of I1
+//       pass B  rows I2, columns C1, written over the (dead) I1 x C1 block -> 2 * sum over i in I1, e in I2
+//       pass C  rows I2, columns C2, written over the (dead) I1 x C2 block -> sum over I2 x I2 and the diagonal of I2
+//     LDS holds n/2 rows of a full 16-slot tile (the footprint of the half-slot mode it replaces); rows of I2 are loaded twice.
+// =====================================================================================
+template <typename T, int NT>
+__global__ void __launch_bounds__(256) k_det_trace_mfma_split(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
+                                                              int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
+                                                              T* __restrict__ TR, size_t tr_stride, size_t tr_off,
+                                                              T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+    typedef typename Acc4<T>::type acc_t;
+    constexpr int KSMAX = 4 * NT, NG = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int P = S.P, n = S.det_n[ch], n2 = 2 * n, nks = n2 / 4, h = n / 2, nth = n / 16;      // nth: accumulator tiles per column half
+    T* Y = reinterpret_cast<T*>(smem_raw);               // [h][2n][16]
+    Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)h * n2 * 16);   // [256]
+    const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
+    const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
+    T* Tw = TR + (size_t)w * tr_stride + tr_off + (size_t)kdet * 2 * P;
+    T af[NT][KSMAX];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+            const int np = 16 * nt + lr, kp = 4 * ks + lq;
+            T v = 0;
+            if (np < n2 && ks < nks) {
+                const int e = np >> 1, rip = np & 1, m = kp >> 1, ri = kp & 1;
+                const T re = Iw[(m * n + e) * 2], im = Iw[(m * n + e) * 2 + 1];
+                v = (ri == rip) ? re : (rip == 0 ? -im : im);
+            }
+            af[nt][ks] = v;
+        }
+    Cx<T> y2(0, 0);
+    const int d = tid & 15, g = tid >> 4;
+    for (int st = 0; st < P / 16; ++st) {
+        const int slot = 16 * st + d;
+        const bool live = slot >= 1 && slot < S.D;
+        Cx<T> trc(0, 0);
+        for (int pass = 0; pass < 3; ++pass) {
+            // products of this pass: rows i0..i0+h-1, accumulator tiles [NT0, NT1) (compile-time), stored at row (i - i0) of Y
+            const int i0 = pass == 0 ? 0 : h;
+            auto products = [&](auto t0, auto t1) {
+                constexpr int NT0 = decltype(t0)::value, NT1 = decltype(t1)::value, NTP = NT1 - NT0;
+                T bc[KSMAX], bn[KSMAX];
+                auto load_row = [&](T (&b)[KSMAX], int i) {
+                    const T* xp = Mw + ((size_t)st * n * n2 + (size_t)i * n2 + lq) * 16 + lr;
+#pragma unroll
+                    for (int ks = 0; ks < KSMAX; ++ks) b[ks] = ks < nks ? xp[(size_t)(4 * ks) * 16] : T(0);
+                };
+                if (wave < h) load_row(bc, i0 + wave);
+                for (int ii = wave; ii < h; ii += 4) {
+                    if (ii + 4 < h) load_row(bn, i0 + ii + 4);
+                    acc_t acc[NTP];
+#pragma unroll
+                    for (int nt = 0; nt < NTP; ++nt) acc[nt] = acc_t{0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < KSMAX; ++ks) {
+                        if (ks < nks) {
+#pragma unroll
+                            for (int nt = 0; nt < NTP; ++nt) acc[nt] = mfma16(af[NT0 + nt][ks], bc[ks], acc[nt]);
+                        }
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KSMAX; ++ks) bc[ks] = bn[ks];
+#pragma unroll
+                    for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Y[((size_t)ii * n2 + 16 * (NT0 + nt) + acc_row<T>(lane, r)) * 16 + lr] = acc[nt][r];
+                }
+            };
+            // (the launcher guarantees 2 * nth == NT: n = 8 NT)
+            if (pass == 0) products(std::integral_constant<int, 0>(), std::integral_constant<int, NT>());
+            else if (pass == 1) products(std::integral_constant<int, 0>(), std::integral_constant<int, NT / 2>());
+            else products(std::integral_constant<int, NT / 2>(), std::integral_constant<int, NT>());
+            __syncthreads();
+            // pairs of this pass.  Y row index = electron - (h if the electron is in I2); the column keeps its global index
+            if (pass == 1) {          // i in I1 (rows still from pass A, columns C2), e in I2 (rows from pass B, columns C1): weight 2
+                for (int pi = g; pi < h * h && slot >= 2; pi += NG) {
+                    const int i = pi / h, e = h + pi % h;
+                    const Cx<T> yie(Y[((size_t)i * n2 + 2 * e) * 16 + d], Y[((size_t)i * n2 + 2 * e + 1) * 16 + d]);
+                    const Cx<T> yei(Y[((size_t)(e - h) * n2 + 2 * i) * 16 + d], Y[((size_t)(e - h) * n2 + 2 * i + 1) * 16 + d]);
+                    y2 = cx_fma(T(2) * yie, yei, y2);
+                }
+            } else {                  // upper triangle of the diagonal block (electrons off .. off + h - 1)
+                const int off = pass == 0 ? 0 : h;
+                // rows r and h-1-r of the triangle hold h+1 entries together: a rectangle (h/2) x (h+1), no search
+                for (int pi = g; pi < (h / 2) * (h + 1); pi += NG) {
+                    const int rr = pi / (h + 1), tt = pi - rr * (h + 1);
+                    const int r = tt < h - rr ? rr : h - 1 - rr, t = tt < h - rr ? tt : tt - (h - rr);
+                    const int i = off + r, e = off + r + t;
+                    const Cx<T> yie(Y[((size_t)r * n2 + 2 * e) * 16 + d], Y[((size_t)r * n2 + 2 * e + 1) * 16 + d]);
+                    if (i == e) trc = trc + yie;
+                    if (slot >= 2) {
+                        const Cx<T> yei(Y[((size_t)(e - off) * n2 + 2 * i) * 16 + d], Y[((size_t)(e - off) * n2 + 2 * i + 1) * 16 + d]);
+                        y2 = cx_fma((i != e ? T(2) : T(1)) * yie, yei, y2);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        red[tid] = trc;
+        __syncthreads();
+        if (g == 0 && live) {
+            Cx<T> t(0, 0);
+            for (int q = 0; q < NG; ++q) t = t + red[q * 16 + d];
+            Tw[slot] = t.re;
+            Tw[P + slot] = t.im;
+        }
+        __syncthreads();
+    }
+    red[tid] = y2;
+    __syncthreads();
+    if (tid == 0) {
+        Cx<T> t(0, 0);
+        for (int q = 0; q < 256; ++q) t = t + red[q];
+        T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
+        dw[2] = t.re;
+        dw[3] = t.im;
+    }
+}
+
+// =====================================================================================
 // 5c. combine determinants (network.py:395-427 log-sum-exp) and assemble
 //        E_kin = -1/2 sum_k w_k [ lap log D_k + sum_d (d_d log D_k)^2 ],  w_k = D_k / sum D
 //     (equals the -1/2 sum_d [d_d^2 f + (d_d f)^2] of hamiltonian.py:59-68)
