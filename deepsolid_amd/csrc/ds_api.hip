@@ -1136,8 +1136,8 @@ void ds_system_destroy(ds_system* s) {
         if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->blob64) hipFree(s->blob64);
-    if (s->blob32) hipFree(s->blob32);
+    if (s->blob64) (void)hipFree(s->blob64);
+    if (s->blob32) (void)hipFree(s->blob32);
     delete s;
 }
 

@@ -247,16 +247,21 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                     // MOUT is slot-tile major: [det][slot tile][elec][orb][re,im][16]
                     T* mo = Mw + (size_t)kdet * oe.n * oe.n * 2 * P + (((size_t)(oe.row0 + tile) * oe.n + m) * 2) * 16 + lr;
                     const size_t tstride = (size_t)oe.n * oe.n * 2 * 16;
+                    // the electron's own three coordinate slots live in slot tile(s) st0 (.. st1), workgroup-uniform: only those
+                    // tiles pay for the lane selects; the Laplacian slot is lane 1 of tile 0
+                    const Cx<T> t0 = f0 * qg0, t1 = f0 * qg1, t2 = f0 * qg2;
+                    const int st0 = so >> 4, st1 = (so + 2) >> 4;
 #pragma unroll
                     for (int s = 0; s < ST; ++s) {
-                        const int slot = 16 * s + lr;
-                        Cx<T> v = phi[s] * qv;
-                        if (slot == 1) v = lap;
-                        else if (slot == so) v = v + f0 * qg0;
-                        else if (slot == so + 1) v = v + f0 * qg1;
-                        else if (slot == so + 2) v = v + f0 * qg2;
-                        mo[s * tstride] = v.re;
-                        mo[s * tstride + 16] = v.im;
+                        T vr = phi[s].re * qv.re - phi[s].im * qv.im, vi = phi[s].re * qv.im + phi[s].im * qv.re;
+                        if (s == st0 || s == st1) {
+                            const int dsl = 16 * s + lr - so;
+                            vr += dsl == 0 ? t0.re : (dsl == 1 ? t1.re : (dsl == 2 ? t2.re : T(0)));
+                            vi += dsl == 0 ? t0.im : (dsl == 1 ? t1.im : (dsl == 2 ? t2.im : T(0)));
+                        }
+                        if (s == 0) { vr = lr == 1 ? lap.re : vr; vi = lr == 1 ? lap.im : vi; }
+                        mo[s * tstride] = vr;
+                        mo[s * tstride + 16] = vi;
                     }
                 }
             }
