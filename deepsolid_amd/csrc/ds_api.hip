@@ -1072,10 +1072,6 @@ int check_arch(const ds_system_desc* d) {
     if (d->n_dn > d->n_up) return fail("n_dn > n_up is not supported");
     if (d->n_layers < 1 || d->n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
     if (d->n_det < 1 || d->n_det > 32) return fail("n_det must be in 1..32");
-    {
-        const int no0 = d->full_det ? d->n_up + d->n_dn : d->n_up, no1 = d->full_det ? d->n_up + d->n_dn : d->n_dn;
-        if ((no0 * d->n_det) % 8 || (d->n_dn && (no1 * d->n_det) % 8)) return fail("orbitals per determinant x n_det must be a multiple of 8");
-    }
     if (d->n_sym < 3 || d->n_sym > DS_MAX_SYM) return fail("bad n_sym");
     return 0;
 }

@@ -122,4 +122,15 @@ CASES = {
     'graphene_hex':  dict(system='graphene', seed=28, batch=2, system_kw=dict(S=1), sym_type='hexagonal', mcmc=False,
                           ke_walkers=2, grad_walkers=2),
     'bcc_li_bcc':    dict(system='bcc_li', seed=29, batch=2, sym_type='bcc', mcmc=False, ke_walkers=2),
+    # a fully spin-polarised cell: the empty spin channel is dropped everywhere (network.py:327-328, :537-541)
+    # determinant counts that do not fill the orbital head's 8-orbital column tiles (3 x 2 = 6 orbitals per spin; 1 x 12)
+    'lih_det3':      dict(system='lih', seed=31, batch=3, net_kw=dict(determinants=3), mcmc=False, samplers=False, ke_walkers=3, grad_walkers=3),
+    'bcc_li_det1':   dict(system='bcc_li', seed=32, batch=2, net_kw=dict(determinants=1), mcmc=False, samplers=False, ke_walkers=2, grad_walkers=2),
+    # other layer widths: narrow streams, and widths that change from layer to layer (no residual connection there, network.py:519)
+    'lih_narrow':    dict(system='lih', seed=33, batch=3, net_kw=dict(hidden_dims=((128, 16), (128, 16), (128, 16))), mcmc=False,
+                          samplers=False, ke_walkers=3, grad_walkers=3),
+    'lih_mixed':     dict(system='lih', seed=34, batch=3, net_kw=dict(hidden_dims=((256, 32), (128, 16), (192, 32), (192, 32))), mcmc=False,
+                          samplers=False, ke_walkers=3, grad_walkers=3),
+    'li_polarized':  dict(system='bcc_li', seed=30, batch=3, system_kw=dict(S=1, nelec=(3, 0)), mcmc=False, samplers=False,
+                          ke_walkers=3, grad_walkers=3),
 }

@@ -150,7 +150,10 @@ def test_stages_vs_forward_laplacian_oracle(name):
 OPTION_CASES = ['lih_lastlayer', 'lih_tri', 'lih_fulldet', 'lih_diagenv', 'lih_fullenv', 'lih_bias', 'lih_fn_defaults', 'bcc_li_fulldet']
 
 
-SYM_CASES = ['lih_fcc', 'graphene_hex', 'bcc_li_bcc']      # feature lattices with 4 and 6 rows (supercell.py:103-129)
+SYM_CASES = ['lih_fcc', 'graphene_hex', 'bcc_li_bcc',      # feature lattices with 4 and 6 rows (supercell.py:103-129)
+             'li_polarized',                               # n_dn = 0: one spin channel
+             'lih_det3', 'bcc_li_det1',                    # orbitals x determinants not a multiple of 8
+             'lih_narrow', 'lih_mixed']                    # other layer widths, layers without residual connection
 
 
 @pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'] + OPTION_CASES + SYM_CASES)

@@ -168,7 +168,7 @@ def test_oracle_parameter_gradient_vs_reference_finite_differences(name):
 # torch-backed `jax` stand-in (tools/jax_torch_standin.py, tools/make_golden.py): ke_ref / grad_ref.
 KE_CASES = [c for c in ALL if CASES[c].get('ke_walkers')]
 GRAD_CASES = [c for c in ALL if CASES[c].get('grad_walkers')]
-CPU_GRAD_CASES = ('h2', 'lih', 'lih_fulldet', 'lih_fullenv', 'bcc_li')
+CPU_GRAD_CASES = ('h2', 'lih', 'lih_fulldet', 'lih_fullenv', 'bcc_li', 'li_polarized')
 KE_TOL_HA = 1e-9          # the kinetic-energy pin of the oracle against the reference (Hartree)
 
 
