@@ -90,7 +90,8 @@ template <int N, typename T> __device__ __forceinline__ T row16_bcast_dyn(T v, i
 // 3.5e-16 (the host libm: 3.0e-16).  ~45 instructions.
 __device__ __forceinline__ double ds_tanh(double x) {
     const double ax = fabs(x);
-    const double t = ax + ax;
+    double t = ax + ax;
+    t = t > 80.0 ? 80.0 : t;                                      // tanh is 1 to the last bit beyond; keeps inf finite, NaN stays NaN
     const double kf = rint(t * 1.4426950408889634074);
     double r = fma(kf, -6.93147180369123816490e-01, t);
     r = fma(kf, -1.90821492927058770002e-10, r);

@@ -337,3 +337,22 @@ def test_network_options_local_energy_vs_autodiff_oracle(name):
     for b in range(nb):
         ref = complex(sum(ke_o(p_cpu, tt(fx['x'][b]))))
         assert abs(complex(ke[b].cpu()) - ref) < 1e-8 * max(1.0, abs(ref)), (complex(ke[b].cpu()), ref)
+
+
+def test_tanh_extreme_arguments():
+    """ds_tanh (csrc/ds_device.h) through the value chain's pair layer is covered by every parity test; its edge cases are
+    checked here through a one-layer identity: huge pre-activations must give +-1, not NaN (2|x| overflows the range reduction
+    without the clamp), and NaN must stay NaN.  Uses the bias of layer 0 to drive the pre-activations."""
+    from deepsolid_amd import network
+    fx, cell, klist, net_kw, params = load_case('lih')
+    dp = dev_params(params)
+    net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', **net_kw)
+    x = torch.as_tensor(fx['x'][:2], device='cuda')
+    base = net.apply(dp, x)
+    big = {k: [{kk: vv.clone() for kk, vv in d.items()} for d in v] for k, v in dp.items()}
+    big['single'][0]['b'][:] = 1e300
+    big['double'][0]['b'][:] = -1e300
+    out = net.apply(big, x)
+    assert torch.isfinite(out).all() and torch.isfinite(base).all()
+    big['single'][0]['b'][0] = float('nan')
+    assert torch.isnan(net.apply(big, x)).all()
