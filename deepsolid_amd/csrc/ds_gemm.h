@@ -260,8 +260,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                             vi += dsl == 0 ? t0.im : (dsl == 1 ? t1.im : (dsl == 2 ? t2.im : T(0)));
                         }
                         if (s == 0) { vr = lr == 1 ? lap.re : vr; vi = lr == 1 ? lap.im : vi; }
-                        mo[s * tstride] = vr;
-                        mo[s * tstride + 16] = vi;
+                        __builtin_nontemporal_store(vr, &mo[s * tstride]);          // MOUT is read again only by the determinant kernels
+                        __builtin_nontemporal_store(vi, &mo[s * tstride + 16]);
                     }
                 }
             }
@@ -339,7 +339,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 T o = d1 * z[s];
                 if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
                 if (EPI == 2) o = (hv[s] + o) * rs2;
-                Go[n * P + 16 * s] = o;
+                __builtin_nontemporal_store(o, &Go[n * P + 16 * s]);      // streamed out: the next reader comes after the whole launch
             }
         }
     }
