@@ -717,7 +717,7 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
     const ds::SysDev<T>& S = dev<T>(s);
     int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T));
     if (chunk < 1) return fail("workspace too small: %lld bytes < %zu per walker", (long long)ws_bytes, s->ws.per_walker * sizeof(T));
-    if (s->n_streams == 2 && chunk >= 2 && B > chunk / 2 && !s->prof_on) {
+    if (s->n_streams == 2 && chunk >= 2 && B > chunk / 2) {
         // two half-size workspaces, chunks alternate between two side streams
         const int64_t half = chunk / 2;
         const size_t half_bytes = ((size_t)half * s->ws.per_walker * sizeof(T) + 255) / 256 * 256;
@@ -1113,9 +1113,20 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     if (s->n_streams == 2) {
         bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; k < 2 && ok; ++k)
-            ok = hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming) == hipSuccess;
+        // DS_CUMASK=1: each side stream owns one half of the CU mask bits (experiment: chunks at different phases on disjoint CUs)
+        const char* cm = getenv("DS_CUMASK");
+        for (int k = 0; k < 2 && ok; ++k) {
+            if (cm && atoi(cm) > 0) {
+                uint32_t mask[8];
+                const int mode = atoi(cm);
+                for (int i = 0; i < 8; ++i)
+                    mask[i] = mode == 1 ? ((i < 4) == (k == 0) ? 0xffffffffu : 0u)            // lower / upper 128 bits
+                                        : (k == 0 ? 0x55555555u : 0xaaaaaaaau);                // even / odd bits
+                ok = hipExtStreamCreateWithCUMask(&s->side[k], 8, mask) == hipSuccess;
+            } else
+                ok = hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming) == hipSuccess;
+        }
         if (!ok) {
             ds_system_destroy(s);
             return fail("DS_STREAMS=2: creating the side streams / events failed");
