@@ -188,7 +188,7 @@ def test_local_energy_vs_oracle(name):
         ke, ew = hamiltonian.local_energy_seperate(net.apply, cell, mode=mode, partition_number=3 if (3 * sum(cell.nelec)) % 3 == 0 else 2)(dp, x)
     ke, ew = ke.cpu().numpy(), ew.cpu().numpy()
     onet_ = oracle_net(cell, klist, net_kw, 'eval_logdet')
-    mode = 'for' if sum(cell.nelec) <= 8 else 'hessian'
+    mode = 'for' if sum(cell.nelec) <= 4 else 'hessian'
     el = oham.local_energy_seperate(onet_.apply, cell, mode=mode)
     for b in range(min(2, x.shape[0])):
         k_ref, e_ref = el(p_cpu, tt(fx['x'][b]))
@@ -297,7 +297,7 @@ def test_float32_error_budget(name):
     worse of the two float32 restatements (+1e-6 relative floor); the numbers are printed for the record."""
     from deepsolid_amd import hamiltonian, network
     fx, cell, klist, net_kw, params = load_case(name)
-    nb = 2
+    nb = 1 if name == 'diamond' else 2
     dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v]
           for k, v in params.items()}
     x32 = torch.as_tensor(fx['x'][:nb], dtype=torch.float32)

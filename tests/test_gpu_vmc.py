@@ -71,7 +71,7 @@ def test_total_energy_vs_oracle(name):
     x = torch.as_tensor(fx['x'], device='cuda')
     loss, aux = train.make_loss(net.apply, None, cell)(dp, x)
     o_loss, o_aux = otrain.make_loss(oracle_net(cell, klist, net_kw, 'eval_logdet').apply, cell,
-                                     mode='for' if name == 'lih' else 'hessian')(onet.params_to_torch(params), tt(fx['x']))
+                                     mode='hessian')(onet.params_to_torch(params), tt(fx['x']))
     assert abs(float(loss) - float(o_loss)) < 1e-8
     assert abs(float(aux.imaginary) - float(o_aux.imaginary)) < 1e-8
     assert abs(float(aux.variance) - float(o_aux.variance)) < 1e-7 * max(1.0, abs(float(o_aux.variance)))
