@@ -301,7 +301,7 @@ template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
 
 // workgroup size and grid.z of k_jet_gemm<NB>: at most 1024/NB threads (= its launch bound) per workgroup
 inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz, int ST = 0) {
-    const int nw = Nout / (16 * NB), wmax = (NB == 3 || ST > 10) ? 4 : 1024 / NB / 64;
+    const int nw = Nout / (16 * NB), wmax = (NB == 3 || ST > 5) ? 4 : 1024 / NB / 64;
     int wpb = nw < wmax ? nw : wmax;
     // prefer a multiple of 4 waves per workgroup that divides the wave count: every SIMD then holds the same
     // number of waves (a SIMD with a single wave reaches only 3/4 of the MFMA issue rate)
@@ -397,11 +397,11 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 // ... then the N electron tiles with the fused epilogue
                 ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
                 if (res)
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N, (unsigned)Bc, gz), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
                                        (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
                 else
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N, (unsigned)Bc, gz), block, 0, st, c.G[gi], gws, gts,
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
                                        (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
             }
@@ -443,12 +443,12 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             if (NB == 4 && ST <= 5 && OC % 256 != 0 && OC % 192 == 0) {
                 dim3 b3; unsigned gz3;
                 gemm_geom(OC, 3, &b3, &gz3);
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, 3, (ST <= 5 ? ST : 1), 5>), dim3(ns, (unsigned)Bc, gz3), b3, 0, st,
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, 3, (ST <= 5 ? ST : 1), 5>), dim3(ns * gz3, (unsigned)Bc, 1), b3, 0, st,
                                    c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
                                    blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
                                    (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
             } else
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 5>), dim3(ns, (unsigned)Bc, gz), block, 0, st,
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 5>), dim3(ns * gz, (unsigned)Bc, 1), block, 0, st,
                                c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
                                blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
                                (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);

@@ -34,10 +34,10 @@ template <typename T> struct OrbEpi {
 // its B operand, and the lane that needs X[n][slot] in the epilogue is a lane that held it in its operand registers at
 // k-step n / 4.  The first stash_blocks() 16-row blocks are parked in LDS on the way (one ds_write per operand, no extra
 // global traffic); only the remaining blocks are re-read from memory in the epilogue.  Budget: half of the CU's 160 KB
-// when two workgroups share a CU (NB >= 3, ST <= 10), all of it otherwise.
+// when two workgroups share a CU (ST <= 10), all of it otherwise.
 template <typename T, int NB, int ST> constexpr int stash_blocks() {
-    constexpr int waves = (NB == 3 || ST > 10) ? 4 : 16 / NB;
-    constexpr int budget = (NB >= 3 && ST <= 10 ? 80 : 160) * 1024;           // one workgroup per CU unless NB >= 3, ST <= 10 (two)
+    constexpr int waves = (NB == 3 || ST > 5) ? 4 : 16 / NB;
+    constexpr int budget = (ST <= 10 ? 80 : 160) * 1024;                      // two workgroups per CU unless ST > 10 (one)
     constexpr int per_block = waves * 4 * ST * 64 * (int)sizeof(T);
     return budget / per_block > NB ? NB : budget / per_block;
 }
@@ -72,7 +72,7 @@ __host__ __device__ constexpr bool gemm_uses_ring(int epi) { return epi == 0 || 
 //            phase 5-jet of the tile's electron) with the product rule, stored into MOUT.
 template <typename T, int NB, int ST, int EPI>
 // (very wide slot ranges, ST > 10: four waves per workgroup so that a wave may use the whole register file)
-__global__ void __launch_bounds__((NB == 3 || ST > 10 ? 256 : 1024 / NB), (NB >= 3 && ST <= 10 ? 2 : 1))
+__global__ void __launch_bounds__((NB == 3 || ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1))
 k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride, const T* __restrict__ W, int K,
            const T* __restrict__ X2, size_t x2_walker_stride, const T* __restrict__ W2, int K2, int n_tiles,
            T* __restrict__ Z, size_t z_walker_stride, int Nout, int P, const T* __restrict__ Sb,
@@ -89,7 +89,14 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         tile = q % gridDim.x;
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // (wave-uniform values in SGPRs)
-    const int lr = lane & 15, lq = lane >> 4, n0 = (blockIdx.z * (blockDim.x >> 6) + wave) * 16 * NB;
+    // (layer launches fold the column blocks into grid.x: the workgroups sharing an electron tile then run side by side on one XCD)
+    int zb = blockIdx.z;
+    if ((EPI == 1 || EPI == 2 || EPI == 5) && gridDim.x > (unsigned)n_tiles) {
+        const int gzf = gridDim.x / n_tiles;
+        zb = tile % gzf;
+        tile /= gzf;
+    }
+    const int lr = lane & 15, lq = lane >> 4, n0 = (zb * (blockDim.x >> 6) + wave) * 16 * NB;
     if (n0 >= Nout) return;                      // column blocks beyond Nout (grid.z rounds up)
     const T* Xp;
     const T* Wp;
