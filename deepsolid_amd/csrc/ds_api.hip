@@ -311,6 +311,13 @@ inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz, int ST = 0) {
     *gz = (unsigned)((nw + wpb - 1) / wpb);
 }
 
+// k_m2_expand: feature splits (grid.z) so that a workgroup's pair jets take at most ~8 KB of LDS
+template <typename T> inline unsigned m2_split(int K2, int N) {
+    unsigned z = 1;
+    while (z < 8 && K2 % (2 * z) == 0 && (size_t)(K2 / z) * 5 * N * sizeof(T) > 8192) z *= 2;
+    return z;
+}
+
 enum Stop { STOP_NONE = 0, STOP_G0, STOP_G1, STOP_G2, STOP_G3, STOP_H2_0, STOP_H2_1, STOP_H2_2, STOP_MEAN0, STOP_Q,
             STOP_MOUT, STOP_MINV, STOP_DETS, STOP_TR };
 
@@ -349,7 +356,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
         {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
-            hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) * sizeof(T), st, S,
+            hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
                                c.H2[hi], K2, c.G[gi], Kh);
         }
         if (stop == STOP_G0 + l) return copy_out(dr, c.G[gi], L.G * Bc, st);
@@ -418,7 +425,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
     if (s->use_last) {
         ProfScope ps(s, DS_PROF_M2_EXPAND, st);
-        hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc), dim3(256), (size_t)(K2l * 5 * S.N + S.nch * K2l * 5) * sizeof(T), st, S,
+        hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2l, S.N)), dim3(256), (size_t)(K2l * 5 * S.N + S.nch * K2l * 5) / m2_split<T>(K2l, S.N) * sizeof(T), st, S,
                            c.H2[hi], K2l, c.G[gi], Kl);
     }
     for (int sp = 0; sp < S.nch; ++sp) {

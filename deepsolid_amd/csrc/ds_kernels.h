@@ -195,18 +195,20 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
 // 2a. spin means of the two-electron stream -> rows [h1, h1 + nch*h2) of G   (network.py:305-332)
 //     expands the 5-slot pair jets to dense slots:  d/dx_i = +d/dr, d/dx_j = -d/dr
 // =====================================================================================
+// grid.z splits the K2 pair features (the pair jets of a split then fit several workgroups' worth of LDS per CU)
 template <typename T>
 __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restrict__ H2, int K2, T* __restrict__ G, int row0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int e = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int N = S.N, P = S.P, NP = S.NP;
-    T* hs = reinterpret_cast<T*>(smem_raw);     // [K2*5][N]  pair jets h2[j][e], j = 0..N-1
-    T* sums = hs + K2 * 5 * N;                  // [nch][K2][5]
-    const T* Hw = H2 + (size_t)w * K2 * 5 * NP + (size_t)e * N;
-    for (int idx = tid; idx < K2 * 5 * N; idx += nt) hs[idx] = Hw[(size_t)(idx / N) * NP + idx % N];
+    const int Kc = K2 / gridDim.z, k0 = blockIdx.z * Kc;      // this workgroup's features
+    T* hs = reinterpret_cast<T*>(smem_raw);     // [Kc*5][N]  pair jets h2[j][e], j = 0..N-1
+    T* sums = hs + Kc * 5 * N;                  // [nch][Kc][5]
+    const T* Hw = H2 + ((size_t)w * K2 + k0) * 5 * NP + (size_t)e * N;
+    for (int idx = tid; idx < Kc * 5 * N; idx += nt) hs[idx] = Hw[(size_t)(idx / N) * NP + idx % N];
     __syncthreads();
-    for (int idx = tid; idx < S.nch * K2 * 5; idx += nt) {
-        const int kc = idx % (5 * K2), s = idx / (5 * K2);
+    for (int idx = tid; idx < S.nch * Kc * 5; idx += nt) {
+        const int kc = idx % (5 * Kc), s = idx / (5 * Kc);
         const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
         T v = 0;
         for (int j = j0; j < j0 + ns; ++j) v += hs[kc * N + j];
@@ -214,15 +216,15 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
     }
     __syncthreads();
     // h2[j][e] depends on r = x_j - x_e: d/dx_j = +d/dr, d/dx_e = -d/dr
-    T* Ge = G + ((size_t)(w * N + e) * S.ldk + row0) * P;
+    T* Ge = G + ((size_t)(w * N + e) * S.ldk + row0 + k0) * P;
     // a thread produces four consecutive slots of one row (32-byte store; one division per four elements)
     typedef T vec4 __attribute__((ext_vector_type(4)));
     const int QP = P / 4;
-    for (int idx = tid; idx < S.nch * K2 * QP; idx += nt) {
-        const int row = idx / QP, sq = idx - row * QP, k = row % K2, s = row / K2;
+    for (int idx = tid; idx < S.nch * Kc * QP; idx += nt) {
+        const int row = idx / QP, sq = idx - row * QP, k = row % Kc, s = row / Kc;
         const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
         const T inv = T(1) / T(ns);
-        const T* sm = sums + (s * K2 + k) * 5;
+        const T* sm = sums + (s * Kc + k) * 5;
         vec4 v;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
             }
             v[u] = x;
         }
-        *reinterpret_cast<vec4*>(Ge + (size_t)row * P + 4 * sq) = v;
+        *reinterpret_cast<vec4*>(Ge + ((size_t)s * K2 + k) * P + 4 * sq) = v;
     }
 }
 
