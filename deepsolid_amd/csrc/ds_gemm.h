@@ -382,7 +382,7 @@ k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, i
         typedef T vec4 __attribute__((ext_vector_type(4)));          // P is a multiple of 16: every row is 128-byte aligned
         for (int e = tid; e < KC * P / 4; e += nthr) {
             vec4 v = {0, 0, 0, 0};
-#pragma unroll 4
+#pragma unroll 6
             for (int i = 0; i < ns; ++i) v += *reinterpret_cast<const vec4*>(g0 + (size_t)i * S.ldk * P + 4 * e);
             *reinterpret_cast<vec4*>(dst + 4 * e) = v * inv;
         }
