@@ -485,25 +485,29 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                            L.dets_off[sp]);                                                                                    \
     } while (0)
         // matrix-core version when the real expansion (2n) is a whole number of k-steps and a slot tile (or half of one) of Y fits LDS
-        const size_t ybytes16 = (size_t)n * 2 * n * 16 * sizeof(T) + 256 * sizeof(ds::Cx<T>);
-        const size_t ybytes8 = (size_t)n * 2 * n * 8 * sizeof(T) + 256 * sizeof(ds::Cx<T>);
         const int nt = (2 * n + 15) / 16;
-        const bool sw8 = ybytes16 > 150 * 1024;
+        // (nt >= 3: 8-wave workgroups, one per CU at these sizes; their [512] reduction buffer is counted for all)
+        const size_t ybytes16 = (size_t)n * 2 * n * 16 * sizeof(T) + 512 * sizeof(ds::Cx<T>);
+        const size_t ybytes8 = (size_t)n * 2 * n * 8 * sizeof(T) + 512 * sizeof(ds::Cx<T>);
+        const bool sw8 = ybytes16 > 160 * 1024;
         const size_t ybytes = sw8 ? ybytes8 : ybytes16;
-        if ((2 * n) % 4 == 0 && ybytes <= 150 * 1024 && nt <= 6 && !s->det_valu) {
-#define DS_TRM(NTV, SWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV>), dim3(S.K, (unsigned)Bc), dim3(256), ybytes, st, S, c.MOUT, L.MOUT,  \
+        if ((2 * n) % 4 == 0 && ybytes <= 160 * 1024 && nt <= 6 && !s->det_valu) {
+#define DS_TRM(NTV, SWV, NWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp])
             if (sw8 && (n == 32 || n == 48) && !s->det_half_slots) {
                 // row-split mode: half the rows of a full slot tile in LDS, nothing computed twice
-                const size_t sbytes = (size_t)(n / 2) * 2 * n * 16 * sizeof(T) + 256 * sizeof(ds::Cx<T>);
-#define DS_TRS(NTV) hipLaunchKernelGGL((ds::k_det_trace_mfma_split<T, NTV>), dim3(S.K, (unsigned)Bc), dim3(256), sbytes, st, S, c.MOUT, L.MOUT,  \
+                // (4 waves: the A fragments + three operand sets need the 512-register budget; 8 waves with one set less
+                //  measured slower, 71.3 vs 68.7 ms per diamond step)
+                constexpr int NWS = 4;
+                const size_t sbytes = (size_t)(n / 2) * 2 * n * 16 * sizeof(T) + 512 * sizeof(ds::Cx<T>);
+#define DS_TRS(NTV) hipLaunchKernelGGL((ds::k_det_trace_mfma_split<T, NTV, NWS, (NTV <= 4 || sizeof(T) == 4 ? 2 : 1)>), dim3(S.K, (unsigned)Bc), dim3(64 * NWS), sbytes, st, S, c.MOUT, L.MOUT,  \
                                        L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS, L.dets_off[sp])
                 if (n == 32) DS_TRS(4); else DS_TRS(6);        // 2n = 16 NT exactly
 #undef DS_TRS
-            } else if (sw8) { if (nt <= 4) DS_TRM(4, 8); else DS_TRM(6, 8); }
-            else if (nt == 1) DS_TRM(1, 16); else if (nt == 2) DS_TRM(2, 16); else if (nt == 3) DS_TRM(3, 16); else if (nt == 4) DS_TRM(4, 16);
-            else DS_TRM(6, 16);
+            } else if (sw8) { if (nt <= 4) DS_TRM(4, 8, 4); else DS_TRM(6, 8, 4); }
+            else if (nt == 1) DS_TRM(1, 16, 4); else if (nt == 2) DS_TRM(2, 16, 4); else if (nt == 3) DS_TRM(3, 16, 8); else if (nt == 4) DS_TRM(4, 16, 8);
+            else DS_TRM(6, 16, 4);
 #undef DS_TRM
         } else
         if (n <= 16) DS_TRACE(16, 16);

@@ -533,20 +533,21 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
 // =====================================================================================
 // SW = slots of a 16-slot MFMA tile parked in LDS per pass: 16, or 8 (two passes over the tile, the products are
 // recomputed) when n * 2n * 16 elements do not fit the LDS.
-template <typename T, int NT, int SW>
-__global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
+// NW = waves per workgroup: 8 for the matrices whose Y tile leaves room for one workgroup per CU only (two waves per SIMD).
+template <typename T, int NT, int SW, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                         int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                         T* __restrict__ TR, size_t tr_stride, size_t tr_off,
                                                         T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int KSMAX = 4 * NT;                         // 2n <= 16 NT  ->  2n / 4 <= 4 NT k-steps
-    constexpr int NG = 256 / SW;                          // thread groups of the trace phase
+    constexpr int NTHR = 64 * NW, NG = NTHR / SW;         // NG thread groups in the trace phase
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int P = S.P, n = S.det_n[ch], n2 = 2 * n, nks = n2 / 4;
     T* Y = reinterpret_cast<T*>(smem_raw);               // [n][2n][SW]
-    Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)n * n2 * SW);   // [256]
+    Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)n * n2 * SW);   // [NTHR]
     const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
     const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
     T* Tw = TR + (size_t)w * tr_stride + tr_off + (size_t)kdet * 2 * P;
@@ -567,20 +568,26 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
         }
     Cx<T> y2(0, 0);
     const int d = tid % SW, g = tid / SW;
-    for (int sp = 0; sp < (P / 16) * (16 / SW); ++sp) {
-        const int st = sp / (16 / SW), half = sp % (16 / SW);
-        // B operands of the wave's next two electron rows are requested before the current row's MFMAs (large matrices run one
-        // workgroup per CU: nothing else hides the HBM latency)
-        T bc[KSMAX], bn[KSMAX], bm[KSMAX];
-        auto load_row = [&](T (&b)[KSMAX], int i) {
+    // The wave's rows over ALL slot tiles form one sequence q = (pass, row): the B operands of row q + 2 are requested before
+    // the MFMAs of row q, across the tile boundaries too, so the trace phase of a tile hides the latency of the next tile's
+    // first rows (large matrices run one workgroup per CU: nothing else would).
+    const int nsp = (P / 16) * (16 / SW), R = wave < n ? (n - wave + NW - 1) / NW : 0, total = R * nsp;
+    T bc[KSMAX], bn[KSMAX], bm[KSMAX];
+    auto load_q = [&](T (&b)[KSMAX], int q) {
+        if (q < total) {
+            const int sp = q / R, i = wave + NW * (q - sp * R), st = sp / (16 / SW);
             const T* xp = Mw + ((size_t)st * n * n2 + (size_t)i * n2 + lq) * 16 + lr;      // contiguous n*2n*16 chunk per slot tile
 #pragma unroll
             for (int ks = 0; ks < KSMAX; ++ks) b[ks] = ks < nks ? xp[(size_t)(4 * ks) * 16] : T(0);
-        };
-        if (wave < n) load_row(bc, wave);
-        if (wave + 4 < n) load_row(bn, wave + 4);
-        for (int i = wave; i < n; i += 4) {
-            if (i + 8 < n) load_row(bm, i + 8);
+        }
+    };
+    load_q(bc, 0);
+    load_q(bn, 1);
+    int q = 0;
+    for (int sp = 0; sp < nsp; ++sp) {
+        const int st = sp / (16 / SW), half = sp % (16 / SW);
+        for (int i = wave; i < n; i += NW, ++q) {
+            load_q(bm, q + 2);
             acc_t acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = acc_t{0, 0, 0, 0};
@@ -629,7 +636,7 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
         __syncthreads();
         if (g == 0 && live) {
             Cx<T> t(0, 0);
-            for (int q = 0; q < NG; ++q) t = t + red[q * SW + d];
+            for (int u = 0; u < NG; ++u) t = t + red[u * SW + d];
             Tw[slot] = t.re;
             Tw[P + slot] = t.im;
         }
@@ -639,7 +646,7 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
     __syncthreads();
     if (tid == 0) {
         Cx<T> t(0, 0);
-        for (int q = 0; q < 256; ++q) t = t + red[q];
+        for (int u = 0; u < NTHR; ++u) t = t + red[u];
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
         dw[2] = t.re;
         dw[3] = t.im;
@@ -654,19 +661,20 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma(SysDev<T> S, const T* __
 //       pass C  rows I2, columns C2, written over the (dead) I1 x C2 block -> sum over I2 x I2 and the diagonal of I2
 //     LDS holds n/2 rows of a full 16-slot tile (the footprint of the half-slot mode it replaces); rows of I2 are loaded twice.
 // =====================================================================================
-template <typename T, int NT>
-__global__ void __launch_bounds__(256) k_det_trace_mfma_split(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
+// PF = rows requested ahead (2, or 1 where the A fragments leave no registers for a third operand set)
+template <typename T, int NT, int NW = 4, int PF = 2>
+__global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                               int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                               T* __restrict__ TR, size_t tr_stride, size_t tr_off,
                                                               T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
     typedef typename Acc4<T>::type acc_t;
-    constexpr int KSMAX = 4 * NT, NG = 16;
+    constexpr int KSMAX = 4 * NT, NTHR = 64 * NW, NG = NTHR / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int P = S.P, n = S.det_n[ch], n2 = 2 * n, nks = n2 / 4, h = n / 2, nth = n / 16;      // nth: accumulator tiles per column half
     T* Y = reinterpret_cast<T*>(smem_raw);               // [h][2n][16]
-    Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)h * n2 * 16);   // [256]
+    Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)h * n2 * 16);   // [NTHR]
     const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
     const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
     T* Tw = TR + (size_t)w * tr_stride + tr_off + (size_t)kdet * 2 * P;
@@ -686,24 +694,31 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma_split(SysDev<T> S, const
         }
     Cx<T> y2(0, 0);
     const int d = tid & 15, g = tid >> 4;
+    // The wave's rows over all slot tiles and passes form one sequence q = ((tile, pass), row): the operands of row q + PF are
+    // requested before the MFMAs of row q, across pass and tile boundaries (one workgroup per CU: nothing else hides the latency).
+    const int R = wave < h ? (h - wave + NW - 1) / NW : 0, total = R * 3 * (P / 16);
+    T bc[KSMAX], bn[KSMAX], bm[KSMAX];
+    auto load_q = [&](T (&b)[KSMAX], int q) {
+        if (q < total) {
+            const int tp = q / R, ii = wave + NW * (q - tp * R), st = tp / 3, i = (tp - 3 * st == 0 ? 0 : h) + ii;
+            const T* xp = Mw + ((size_t)st * n * n2 + (size_t)i * n2 + lq) * 16 + lr;
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks) b[ks] = ks < nks ? xp[(size_t)(4 * ks) * 16] : T(0);
+        }
+    };
+    load_q(bc, 0);
+    if (PF == 2) load_q(bn, 1);
+    int q = 0;
     for (int st = 0; st < P / 16; ++st) {
         const int slot = 16 * st + d;
         const bool live = slot >= 1 && slot < S.D;
         Cx<T> trc(0, 0);
         for (int pass = 0; pass < 3; ++pass) {
             // products of this pass: rows i0..i0+h-1, accumulator tiles [NT0, NT1) (compile-time), stored at row (i - i0) of Y
-            const int i0 = pass == 0 ? 0 : h;
             auto products = [&](auto t0, auto t1) {
                 constexpr int NT0 = decltype(t0)::value, NT1 = decltype(t1)::value, NTP = NT1 - NT0;
-                T bc[KSMAX], bn[KSMAX];
-                auto load_row = [&](T (&b)[KSMAX], int i) {
-                    const T* xp = Mw + ((size_t)st * n * n2 + (size_t)i * n2 + lq) * 16 + lr;
-#pragma unroll
-                    for (int ks = 0; ks < KSMAX; ++ks) b[ks] = ks < nks ? xp[(size_t)(4 * ks) * 16] : T(0);
-                };
-                if (wave < h) load_row(bc, i0 + wave);
-                for (int ii = wave; ii < h; ii += 4) {
-                    if (ii + 4 < h) load_row(bn, i0 + ii + 4);
+                for (int ii = wave; ii < h; ii += NW, ++q) {
+                    if (PF == 2) load_q(bm, q + 2); else load_q(bn, q + 1);
                     acc_t acc[NTP];
 #pragma unroll
                     for (int nt = 0; nt < NTP; ++nt) acc[nt] = acc_t{0, 0, 0, 0};
@@ -715,7 +730,7 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma_split(SysDev<T> S, const
                         }
                     }
 #pragma unroll
-                    for (int ks = 0; ks < KSMAX; ++ks) bc[ks] = bn[ks];
+                    for (int ks = 0; ks < KSMAX; ++ks) { bc[ks] = bn[ks]; if (PF == 2) bn[ks] = bm[ks]; }
 #pragma unroll
                     for (int nt = 0; nt < NTP; ++nt)
 #pragma unroll
@@ -756,7 +771,7 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma_split(SysDev<T> S, const
         __syncthreads();
         if (g == 0 && live) {
             Cx<T> t(0, 0);
-            for (int q = 0; q < NG; ++q) t = t + red[q * 16 + d];
+            for (int u = 0; u < NG; ++u) t = t + red[u * 16 + d];
             Tw[slot] = t.re;
             Tw[P + slot] = t.im;
         }
@@ -766,7 +781,7 @@ __global__ void __launch_bounds__(256) k_det_trace_mfma_split(SysDev<T> S, const
     __syncthreads();
     if (tid == 0) {
         Cx<T> t(0, 0);
-        for (int q = 0; q < 256; ++q) t = t + red[q];
+        for (int u = 0; u < NTHR; ++u) t = t + red[u];
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
         dw[2] = t.re;
         dw[3] = t.im;
