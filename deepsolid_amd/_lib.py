@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdeepsolid_hip.so')
+# DEEPSOLID_HIP_LIB: load another build of the SAME library (the sanitizer build of tools/asan_check.sh); still no fallback.
+LIB_PATH = os.environ.get('DEEPSOLID_HIP_LIB') or os.path.join(_HERE, 'libdeepsolid_hip.so')
 
 DS_MAX_LAYERS = 8
 DS_MAX_SYM = 6

@@ -339,3 +339,24 @@ torch.save((torch.view_as_real(ke).cpu(), ew.cpu()), {str(out)!r})
     x = torch.as_tensor(systems.synthetic_walkers(cell, 300, seed=21), device='cuda')
     ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(dp, x)
     assert torch.equal(torch.view_as_real(ke).cpu(), ke2) and torch.equal(ew.cpu(), ew2)
+
+
+def test_bench_under_torchrun_with_rccl_one_rank():
+    """The driver's launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with N = 1 on the
+    GPU box: the process group is RCCL (backend "nccl"), the packed statistics go through a real all-reduce on the device, and
+    the JSON line reports the rank.  (N > 1 needs more GPUs than this box has; the CPU suite covers it with gloo.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29517', os.path.join(root, 'bench.py'), '--gpus', '1', '--system', 'lih', '--batch', '512', '--steps', '2',
+           '--warmup', '1', '--no-cpu-baseline', '--no-mcmc']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['value'] > 0
