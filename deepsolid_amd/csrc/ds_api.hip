@@ -1048,7 +1048,7 @@ inline size_t mcmc_scratch_bytes(const ds_system* s, int64_t B) {
 template <typename T>
 int mcmc_step_impl(ds_system* s, const void* params, void* x_, void* lp_, int64_t B, int steps, double width, uint64_t seed,
                    uint64_t offset, const void* normals_, const void* uniforms_, int lp_valid, void* n_accept, void* ws,
-                   int64_t ws_bytes, hipStream_t st) {
+                   int64_t ws_bytes, hipStream_t st, int first_electron = -1) {
     const ds::SysDev<T>& S = dev<T>(s);
     const size_t head = mcmc_scratch_bytes(s, B);
     if ((int64_t)head >= ws_bytes) return fail("workspace too small for ds_mcmc_step (see ds_mcmc_workspace_bytes)");
@@ -1064,8 +1064,12 @@ int mcmc_step_impl(ds_system* s, const void* params, void* x_, void* lp_, int64_
         hipLaunchKernelGGL((ds::k_scale2<T>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, LA2, (long)B, lp);
     }
     for (int i = 0; i < steps; ++i) {                                    // lax.fori_loop(0, nsteps, ...)   :358
+        // all-electron move, or (first_electron >= 0) move i displaces electron (first_electron + i) % N only  (qmc.py:266)
+        const int only = first_electron < 0 ? -1 : (int)(((int64_t)first_electron + i) % S.N);
+        const size_t nstride = (size_t)B * 3 * (only < 0 ? S.N : 1);
         hipLaunchKernelGGL((ds::k_mcmc_propose<T>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, S.sim_a, S.sim_ainv, x,
-                           normals ? normals + (size_t)i * B * 3 * S.N : (const T*)nullptr, key, (unsigned long long)i, (T)width, ne, X2);
+                           normals ? normals + (size_t)i * nstride : (const T*)nullptr, key, (unsigned long long)i, (T)width, ne, X2,
+                           S.N, only);
         if (int rc = logpsi_impl<T>(s, params, X2, B, LA2, nullptr, wsv, wsv_bytes, st)) return rc;
         hipLaunchKernelGGL((ds::k_mcmc_accept<T>), dim3((unsigned)B), dim3(64), 0, st, x, lp, X2, LA2,
                            uniforms ? uniforms + (size_t)i * B : (const T*)nullptr, key, (unsigned long long)i, 3 * S.N, 0L, (T*)n_accept);
@@ -1364,6 +1368,20 @@ int ds_mcmc_step(ds_system* s, const void* params, void* x, void* lp, int64_t B,
                                                   lp_valid, n_accept, ws, ws_bytes, st)
                          : mcmc_step_impl<float>(s, params, x, lp, B, steps, width, philox_seed, philox_offset, normals, uniforms,
                                                  lp_valid, n_accept, ws, ws_bytes, st);
+}
+
+int ds_mcmc_step_one_electron(ds_system* s, const void* params, void* x, void* lp, int64_t B, int moves, int first_electron,
+                              double width, uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms,
+                              int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream) {
+    if (!s || !params || !x || !lp || !n_accept || !ws) return fail("null argument");
+    if ((normals == nullptr) != (uniforms == nullptr)) return fail("normals and uniforms must be given together (or both NULL)");
+    if (moves < 0 || first_electron < 0) return fail("moves and first_electron must be >= 0");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return s->dtype == 0 ? mcmc_step_impl<double>(s, params, x, lp, B, moves, width, philox_seed, philox_offset, normals, uniforms,
+                                                  lp_valid, n_accept, ws, ws_bytes, st, first_electron)
+                         : mcmc_step_impl<float>(s, params, x, lp, B, moves, width, philox_seed, philox_offset, normals, uniforms,
+                                                 lp_valid, n_accept, ws, ws_bytes, st, first_electron);
 }
 
 int ds_energy_stats(ds_system* s, const void* ke, const void* ewald, int64_t B, double* out_stats, void* stream) {

@@ -67,16 +67,22 @@ __device__ __forceinline__ double philox_uniform(const PhiloxKey k, unsigned lon
     return u53_co(a.v[0], a.v[1]);
 }
 
-// x2 = wrap(x1 + width * N(0,1))      qmc.py:192-193; `normal` != nullptr replays caller-supplied noise (test mode)
+// x2 = wrap(x1 + width * N(0,1))      qmc.py:192-193; `normal` != nullptr replays caller-supplied noise (test mode).
+// only >= 0: one-electron move (qmc.py:266-271): electron `only` of every walker gets the step (explicit noise is then
+// (B,3)), the others are only wrapped, as the reference's enforce_pbc on the whole configuration does.
 template <typename T>
 __global__ void k_mcmc_propose(const T* __restrict__ a, const T* __restrict__ ainv, const T* __restrict__ x1,
                                const T* __restrict__ normal, PhiloxKey key, unsigned long long step, T width, size_t n_elec,
-                               T* __restrict__ x2) {
+                               T* __restrict__ x2, int N = 0, int only = -1) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_elec) return;
     T r[3], o[3], wr[3];
-    if (normal) {
-        for (int c = 0; c < 3; ++c) r[c] = x1[3 * e + c] + width * normal[3 * e + c];
+    const bool moved = only < 0 || (int)(e % (size_t)N) == only;
+    if (!moved) {
+        for (int c = 0; c < 3; ++c) r[c] = x1[3 * e + c];
+    } else if (normal) {
+        const size_t ni = only < 0 ? e : e / (size_t)N;
+        for (int c = 0; c < 3; ++c) r[c] = x1[3 * e + c] + width * normal[3 * ni + c];
     } else {
         double z[3];
         philox_normal3(key, step, e, z);

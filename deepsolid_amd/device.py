@@ -474,10 +474,12 @@ class DeviceSystem:
                                             _ptr(n_accept), _ptr(scratch), _stream()), 'ds_mh_accept_ex')
 
     def mcmc_step(self, params, x, lp, steps, width, seed=0, offset=0, normals=None, uniforms=None, lp_valid=False,
-                  n_accept=None):
+                  n_accept=None, first_electron=None):
         """`ds_mcmc_step`: `steps` all-electron Metropolis moves on x (B,3N) / lp (B,) IN PLACE, enqueued without a host
         synchronisation.  Noise from the in-kernel Philox stream (seed, offset) or replayed from `normals`
-        (steps,B,3N) / `uniforms` (steps,B).  -> n_accept (1,) device tensor (incremented)."""
+        (steps,B,3N) / `uniforms` (steps,B).  -> n_accept (1,) device tensor (incremented).
+        `first_electron` = e: `ds_mcmc_step_one_electron` instead -- move i displaces electron (e + i) % N only
+        (explicit normals are then (steps,B,3))."""
         x = self._check_x(x)
         B = x.shape[0]
         p = self.pack_params(params)
@@ -488,12 +490,20 @@ class DeviceSystem:
         if normals is not None:
             normals = normals.to(device=self.device, dtype=self.dtype).contiguous()
             uniforms = uniforms.to(device=self.device, dtype=self.dtype).contiguous()
-            if tuple(normals.shape) != (steps, B, 3 * self.n) or tuple(uniforms.shape) != (steps, B):
-                raise ValueError('explicit noise must be normals (steps, B, 3N) and uniforms (steps, B)')
+            width3 = 3 * self.n if first_electron is None else 3
+            if tuple(normals.shape) != (steps, B, width3) or tuple(uniforms.shape) != (steps, B):
+                raise ValueError('explicit noise must be normals (steps, B, 3N) -- (steps, B, 3) for one-electron moves -- '
+                                 'and uniforms (steps, B)')
         need = int(self.lib.ds_mcmc_workspace_bytes(self.handle, int(B)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if first_electron is not None:
+            _lib.check(self.lib.ds_mcmc_step_one_electron(
+                self.handle, _ptr(p), _ptr(x), _ptr(lp), B, int(steps), int(first_electron), float(width), int(seed) & (2 ** 64 - 1),
+                int(offset) & (2 ** 64 - 1), _ptr(normals), _ptr(uniforms), int(bool(lp_valid)), _ptr(n_accept), _ptr(self._ws),
+                self._ws.numel(), _stream()), 'ds_mcmc_step_one_electron')
+            return n_accept
         _lib.check(self.lib.ds_mcmc_step(self.handle, _ptr(p), _ptr(x), _ptr(lp), B, int(steps), float(width),
                                          int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _ptr(normals), _ptr(uniforms),
                                          int(bool(lp_valid)), _ptr(n_accept), _ptr(self._ws), self._ws.numel(), _stream()),

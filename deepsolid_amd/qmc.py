@@ -9,8 +9,10 @@ symmetric) runs as ONE C-ABI call, ``ds_mcmc_step``: all `steps` moves are enque
 without touching the host and the noise is a counter-based Philox4x32-10 stream
 evaluated inside the kernels (replacing JAX's threefry, qmc.py:190-192,217-218).
 ``key`` is an int seed or a ``torch.Generator``; explicit noise ``(normals,
-uniforms)`` can be supplied instead for replay tests.  The other samplers draw
-from torch's generator and call the propose / accept kernels per move.
+uniforms)`` can be supplied instead for replay tests.  One-electron moves run
+the same way through ``ds_mcmc_step_one_electron``.  The importance-sampled and
+asymmetric proposals draw from torch's generator and call the propose / accept
+kernels per move.
 
 All three samplers of the reference are available: all-electron Metropolis
 (``mh_update``, the default), one-electron moves (``mh_one_electron_update``) and
@@ -157,31 +159,34 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
         func = batch_slog_network
         inner_fun = mh_one_electron_update if one_electron_moves else mh_update                  # qmc.py:327-333
 
-    fused = importance_sampling is None and not one_electron_moves and atoms is None
+    fused = importance_sampling is None and atoms is None          # default sampler AND one-electron moves: one C-ABI call
     system = batch_slog_network.system
     if fused:
         _check_latvec(latvec, system)
     gen_calls = {}                            # stateful torch.Generator keys: Philox offset advanced by `steps` per call
 
     def fused_step(params, data, key, width):
-        """The default sampler as ONE C-ABI call (`ds_mcmc_step`): proposal, wrap, log|psi|, accept/select for all
-        `steps` moves are enqueued back to back; the noise is Philox evaluated inside the kernels.  `key`: an int is a
+        """The default sampler (`ds_mcmc_step`) or the one-electron sampler (`ds_mcmc_step_one_electron`) as ONE C-ABI call:
+        proposal, wrap, log|psi|, accept/select for all moves are enqueued back to back; the noise is Philox evaluated inside the kernels.  `key`: an int is a
         pure key like a JAX PRNGKey (same key -> same moves; the caller passes a fresh one per iteration, the rank is
         folded in); a torch.Generator is stateful (its initial_seed keys the stream and every call advances the
         offset by `steps`); a tuple (normals, uniforms) replays explicit noise."""
         data = data.clone()
         lp = torch.empty(data.shape[0], dtype=data.dtype, device=data.device)
+        # one-electron moves (`ds_mcmc_step_one_electron`): N * steps moves, move i displaces electron i % N   qmc.py:355-358
+        nsteps = (data.shape[-1] // 3) * steps if one_electron_moves else steps
+        first = 0 if one_electron_moves else None
         if isinstance(key, (tuple, list)):
-            nacc = system.mcmc_step(params, data, lp, steps, width, normals=key[0], uniforms=key[1])
+            nacc = system.mcmc_step(params, data, lp, nsteps, width, normals=key[0], uniforms=key[1], first_electron=first)
         else:
             if isinstance(key, torch.Generator):
                 seed = key.initial_seed()
                 _, off = gen_calls.get(id(key), (key, 0))
-                gen_calls[id(key)] = (key, off + steps)           # (holding the generator keeps its id unique)
+                gen_calls[id(key)] = (key, off + nsteps)          # (holding the generator keeps its id unique)
             else:
                 seed, off = int(key) * max(1, constants.world_size()) + constants.rank(), 0
-            nacc = system.mcmc_step(params, data, lp, steps, width, seed=seed, offset=off)
-        pmove = nacc[0] / (steps * batch_per_device)                              # qmc.py:360
+            nacc = system.mcmc_step(params, data, lp, nsteps, width, seed=seed, offset=off, first_electron=first)
+        pmove = nacc[0] / (nsteps * batch_per_device)                             # qmc.py:360
         return data, constants.pmean_if_pmap(pmove)                              # :361
 
     def mcmc_step(params, data, key, width):

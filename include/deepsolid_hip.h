@@ -206,6 +206,14 @@ int64_t ds_mcmc_workspace_bytes(const ds_system* sys, int64_t B);
 int ds_mcmc_step(ds_system* sys, const void* params, void* x, void* lp, int64_t B, int steps, double width,
                  uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms,
                  int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream);
+/* The same loop with ONE-ELECTRON moves -- qmc.mh_one_electron_update (qmc.py:227-287) as make_mcmc_step drives it
+ * (qmc.py:355-358: nsteps = N * steps, move i displaces electron i % N): move i of this call displaces electron
+ * (first_electron + i) % N of every walker, wraps the whole configuration, evaluates log|psi| and selects.
+ * Philox index of the displaced electron's normals = w * N + electron (the all-electron stream's index of that
+ * electron); test mode: `normals` (moves, B, 3), `uniforms` (moves, B).  pmove = n_accept / (moves * B). */
+int ds_mcmc_step_one_electron(ds_system* sys, const void* params, void* x, void* lp, int64_t B, int moves, int first_electron,
+                              double width, uint64_t philox_seed, uint64_t philox_offset, const void* normals,
+                              const void* uniforms, int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream);
 /* the raw Philox block ds_mcmc_step uses for (seed, offset + step, index, stream_id): host evaluation for tests
  * (stream_id 0 / 1: normal deviates of electron `index`, 2: the uniform deviate of walker `index`). */
 void ds_philox_host(uint64_t seed, uint64_t offset, uint64_t step, uint64_t index, int stream_id, uint32_t out[4]);

@@ -360,3 +360,43 @@ def test_bench_under_torchrun_with_rccl_one_rank():
     assert len(line) == 1
     d = json.loads(line[0])
     assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['value'] > 0
+
+
+@pytest.mark.parametrize('name', ['lih', 'bcc_li'])
+def test_fused_one_electron_sampler(name):
+    """`ds_mcmc_step_one_electron` (make_mcmc_step(one_electron_moves=True), qmc.py:227-287,355-358): with explicit noise it
+    equals the per-move path (`mh_one_electron_update` called N * steps times from Python) bit for bit; with the in-kernel
+    Philox stream a move is a pure function of its key, only the moved electron changes per move, and ranks / keys decorrelate."""
+    from deepsolid_amd import qmc
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    (slog,) = nets(cell, klist, net_kw, 'eval_slogdet')
+    cu = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device='cuda')
+    from deepsolid_amd import distance
+    x0, _ = distance.enforce_pbc(cu(cell.a), cu(fx['mcmc_x0']))          # walkers inside the cell: an unmoved electron stays put
+    B, n3 = x0.shape
+    n = n3 // 3
+    steps, width = 2, 0.25
+    rng = np.random.default_rng(5)
+    nz, un = rng.normal(size=(n * steps, B, 3)), rng.uniform(size=(n * steps, B))
+    step = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=steps, one_electron_moves=True)
+    xf, pf = step(dp, x0, (cu(nz), cu(un)), width)
+    # per-move reference path through the same kernels
+    x, lp = x0.clone(), 2.0 * slog.apply(dp, x0)
+    nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for i in range(n * steps):
+        x, _, lp, nacc = qmc.mh_one_electron_update(dp, slog.apply, x, None, lp, nacc, cell.a, stddev=width, i=i,
+                                                    normal=cu(nz[i]), uniform=cu(un[i]))
+    assert torch.equal(xf, x)
+    assert abs(float(pf) - float(nacc[0]) / (n * steps * B)) < 1e-15
+    # Philox mode
+    xa, pa = step(dp, x0, 11, width)
+    xb, pb = step(dp, x0, 11, width)
+    xc, _ = step(dp, x0, 12, width)
+    assert torch.equal(xa, xb) and float(pa) == float(pb) and not torch.equal(xa, xc)
+    assert 0.0 < float(pa) <= 1.0
+    # one move, first electron 0: electrons 1.. of every walker are untouched (up to the wrap of an already wrapped point)
+    sysd = slog.apply.system
+    x1 = x0.clone(); lp1 = torch.empty(B, dtype=torch.float64, device='cuda')
+    sysd.mcmc_step(dp, x1, lp1, 1, width, seed=3, offset=0, first_electron=0)
+    np.testing.assert_allclose(x1[:, 3:].cpu().numpy(), x0[:, 3:].cpu().numpy(), atol=1e-12)
