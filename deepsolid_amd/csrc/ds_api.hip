@@ -1042,7 +1042,9 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
 // ------------------------------------------------------------------ Metropolis loop (qmc.py:335-362), ds_mcmc.h
 inline size_t mcmc_scratch_bytes(const ds_system* s, int64_t B) {
     const size_t esz = s->dtype == 0 ? 8 : 4;
-    return (((size_t)B * 3 * s->sd.N + (size_t)B) * esz + 255) / 256 * 256;      // proposal x2 (B,3N) + log|psi(x2)| (B,)
+    // proposal x2 (B,3N) + log|psi(x2)| (B,); the importance-sampled loop adds the complex gradient (B,3N,2), the drifts at
+    // x1 / x2, the normal deviates (3 x (B,3N)), the uniforms (B,) and the two batch maxima
+    return (((size_t)B * 3 * s->sd.N * 6 + (size_t)B * 2 + 2) * esz + 255) / 256 * 256;
 }
 
 template <typename T>
@@ -1077,6 +1079,47 @@ int mcmc_step_impl(ds_system* s, const void* params, void* x_, void* lp_, int64_
     HIP_OK(hipGetLastError());
     return 0;
 }
+
+// Drift-biased importance sampling (qmc.importance_update, qmc.py:83-150, as make_mcmc_step drives it): per move the drift
+// grad log|psi| at x1, the proposal x2 = wrap(x1 + w N + w^2 limdrift(g1)), (log|psi|, drift) at x2, and the selection with
+// the forward / reverse proposal densities -- the kernels of ds_mh_propose_ex / ds_mh_accept_ex (mode 2), enqueued back to back.
+template <typename T>
+int mcmc_importance_impl(ds_system* s, const void* params, void* x_, void* lp_, int64_t B, int steps, double width, uint64_t seed,
+                         uint64_t offset, const void* normals_, const void* uniforms_, int lp_valid, void* n_accept, void* ws,
+                         int64_t ws_bytes, hipStream_t st) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const size_t head = mcmc_scratch_bytes(s, B);
+    if ((int64_t)head >= ws_bytes) return fail("workspace too small for ds_mcmc_step_importance (see ds_mcmc_workspace_bytes)");
+    const size_t n3 = (size_t)B * 3 * S.N, ne = (size_t)B * S.N;
+    T* x = (T*)x_; T* lp = (T*)lp_;
+    T* X2 = (T*)ws; T* GC = X2 + n3; T* G1 = GC + 2 * n3; T* G2 = G1 + n3; T* NZ = G2 + n3; T* LA2 = NZ + n3; T* UN = LA2 + B; T* SCR = UN + B;
+    void* wsv = (char*)ws + head;
+    const int64_t wsv_bytes = ws_bytes - (int64_t)head;
+    const ds::PhiloxKey key{seed, offset};
+    const dim3 ge((unsigned)((n3 + 255) / 256)), gn((unsigned)((std::max<size_t>(ne, (size_t)B) + 255) / 256)), blk(256);
+    if (!lp_valid) {                                                     // logprob = 2 f(data)   qmc.py:357
+        if (int rc = logpsi_impl<T>(s, params, x, B, LA2, nullptr, wsv, wsv_bytes, st)) return rc;
+        hipLaunchKernelGGL((ds::k_scale2<T>), dim3((unsigned)((B + 255) / 256)), blk, 0, st, LA2, (long)B, lp);
+    }
+    for (int i = 0; i < steps; ++i) {
+        if (int rc = logpsi_grad_impl<T>(s, params, x, B, LA2, nullptr, GC, wsv, wsv_bytes, st)) return rc;          // :111
+        hipLaunchKernelGGL((ds::k_real_part<T>), ge, blk, 0, st, GC, n3, G1);
+        const T* nz = normals_ ? (const T*)normals_ + (size_t)i * n3 : NZ;
+        const T* un = uniforms_ ? (const T*)uniforms_ + (size_t)i * B : UN;
+        if (!normals_) hipLaunchKernelGGL((ds::k_philox_noise<T>), gn, blk, 0, st, key, (unsigned long long)i, ne, (long)B, NZ, UN);
+        hipLaunchKernelGGL((ds::k_max_norm3<T>), dim3(1), dim3(1024), 0, st, G1, ne, SCR);
+        hipLaunchKernelGGL((ds::k_mh_propose_ex<T>), dim3((unsigned)((ne + 255) / 256)), blk, 0, st, S.sim_a, S.sim_ainv, 2, x, nz, (T)width,
+                           G1, 0, ne, X2, SCR);                                                                      // :112-115
+        if (int rc = logpsi_grad_impl<T>(s, params, X2, B, LA2, nullptr, GC, wsv, wsv_bytes, st)) return rc;         // :118
+        hipLaunchKernelGGL((ds::k_real_part<T>), ge, blk, 0, st, GC, n3, G2);
+        hipLaunchKernelGGL((ds::k_max_norm3<T>), dim3(1), dim3(1024), 0, st, G2, ne, SCR + 1);
+        hipLaunchKernelGGL((ds::k_mh_accept_ex<T>), dim3((unsigned)B), dim3(64), 0, st, 2, x, lp, X2, LA2, un, nz, (T)width, G1, G2, 0, S.N,
+                           (T*)n_accept, SCR);                                                                       // :119-137
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 
 int check_arch(const ds_system_desc* d) {
     if (d->dtype != 0 && d->dtype != 1) return fail("dtype must be 0 (f64) or 1 (f32)");
@@ -1382,6 +1425,20 @@ int ds_mcmc_step_one_electron(ds_system* s, const void* params, void* x, void* l
                                                   lp_valid, n_accept, ws, ws_bytes, st, first_electron)
                          : mcmc_step_impl<float>(s, params, x, lp, B, moves, width, philox_seed, philox_offset, normals, uniforms,
                                                  lp_valid, n_accept, ws, ws_bytes, st, first_electron);
+}
+
+int ds_mcmc_step_importance(ds_system* s, const void* params, void* x, void* lp, int64_t B, int steps, double width,
+                            uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms, int lp_valid,
+                            void* n_accept, void* ws, int64_t ws_bytes, void* stream) {
+    if (!s || !params || !x || !lp || !n_accept || !ws) return fail("null argument");
+    if ((normals == nullptr) != (uniforms == nullptr)) return fail("normals and uniforms must be given together (or both NULL)");
+    if (steps < 0) return fail("steps must be >= 0");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return s->dtype == 0 ? mcmc_importance_impl<double>(s, params, x, lp, B, steps, width, philox_seed, philox_offset, normals, uniforms,
+                                                        lp_valid, n_accept, ws, ws_bytes, st)
+                         : mcmc_importance_impl<float>(s, params, x, lp, B, steps, width, philox_seed, philox_offset, normals, uniforms,
+                                                       lp_valid, n_accept, ws, ws_bytes, st);
 }
 
 int ds_energy_stats(ds_system* s, const void* ke, const void* ewald, int64_t B, double* out_stats, void* stream) {

@@ -216,6 +216,22 @@ __global__ void __launch_bounds__(64) k_mh_accept_ex(int mode, T* __restrict__ x
     }
 }
 
+// helpers of the fused importance-sampled loop (ds_mcmc_step_importance)
+template <typename T> __global__ void k_real_part(const T* __restrict__ gc, size_t n, T* __restrict__ g) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] = gc[2 * i];                       // grad log|psi| = Re of the complex gradient of log psi
+}
+template <typename T> __global__ void k_philox_noise(PhiloxKey key, unsigned long long step, size_t n_elec, long B, T* __restrict__ normal,
+                                                     T* __restrict__ uniform) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_elec) {
+        double z[3];
+        philox_normal3(key, step, e, z);
+        for (int c = 0; c < 3; ++c) normal[3 * e + c] = (T)z[c];
+    }
+    if (e < (size_t)B) uniform[e] = (T)philox_uniform(key, step, (unsigned long long)e);
+}
+
 template <typename T> __global__ void k_scale2(const T* __restrict__ in, long n, T* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = 2 * in[i];

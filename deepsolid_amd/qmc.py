@@ -9,9 +9,10 @@ symmetric) runs as ONE C-ABI call, ``ds_mcmc_step``: all `steps` moves are enque
 without touching the host and the noise is a counter-based Philox4x32-10 stream
 evaluated inside the kernels (replacing JAX's threefry, qmc.py:190-192,217-218).
 ``key`` is an int seed or a ``torch.Generator``; explicit noise ``(normals,
-uniforms)`` can be supplied instead for replay tests.  One-electron moves run
-the same way through ``ds_mcmc_step_one_electron``.  The importance-sampled and
-asymmetric proposals draw from torch's generator and call the propose / accept
+uniforms)`` can be supplied instead for replay tests.  One-electron moves and
+the drift-biased importance-sampled move run the same way
+(``ds_mcmc_step_one_electron``, ``ds_mcmc_step_importance``).  The asymmetric
+``atoms=`` proposal draws from torch's generator and calls the propose / accept
 kernels per move.
 
 All three samplers of the reference are available: all-electron Metropolis
@@ -159,14 +160,17 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
         func = batch_slog_network
         inner_fun = mh_one_electron_update if one_electron_moves else mh_update                  # qmc.py:327-333
 
-    fused = importance_sampling is None and atoms is None          # default sampler AND one-electron moves: one C-ABI call
     system = batch_slog_network.system
+    # all three samplers run as ONE C-ABI call; the importance-sampled one when its drift comes from this system's own network
+    # (process.py:182 passes the same wavefunction) -- a foreign gradient function keeps the per-move path
+    fused = atoms is None and (importance_sampling is None or importance_sampling.system is system)
     if fused:
         _check_latvec(latvec, system)
     gen_calls = {}                            # stateful torch.Generator keys: Philox offset advanced by `steps` per call
 
     def fused_step(params, data, key, width):
-        """The default sampler (`ds_mcmc_step`) or the one-electron sampler (`ds_mcmc_step_one_electron`) as ONE C-ABI call:
+        """The default sampler (`ds_mcmc_step`), the one-electron sampler (`ds_mcmc_step_one_electron`) or the importance-sampled
+        one (`ds_mcmc_step_importance`) as ONE C-ABI call:
         proposal, wrap, log|psi|, accept/select for all moves are enqueued back to back; the noise is Philox evaluated inside the kernels.  `key`: an int is a
         pure key like a JAX PRNGKey (same key -> same moves; the caller passes a fresh one per iteration, the rank is
         folded in); a torch.Generator is stateful (its initial_seed keys the stream and every call advances the
@@ -176,8 +180,10 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
         # one-electron moves (`ds_mcmc_step_one_electron`): N * steps moves, move i displaces electron i % N   qmc.py:355-358
         nsteps = (data.shape[-1] // 3) * steps if one_electron_moves else steps
         first = 0 if one_electron_moves else None
+        imp = importance_sampling is not None
         if isinstance(key, (tuple, list)):
-            nacc = system.mcmc_step(params, data, lp, nsteps, width, normals=key[0], uniforms=key[1], first_electron=first)
+            nacc = system.mcmc_step(params, data, lp, nsteps, width, normals=key[0], uniforms=key[1], first_electron=first,
+                                    importance=imp)
         else:
             if isinstance(key, torch.Generator):
                 seed = key.initial_seed()
@@ -185,7 +191,7 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
                 gen_calls[id(key)] = (key, off + nsteps)          # (holding the generator keeps its id unique)
             else:
                 seed, off = int(key) * max(1, constants.world_size()) + constants.rank(), 0
-            nacc = system.mcmc_step(params, data, lp, nsteps, width, seed=seed, offset=off, first_electron=first)
+            nacc = system.mcmc_step(params, data, lp, nsteps, width, seed=seed, offset=off, first_electron=first, importance=imp)
         pmove = nacc[0] / (nsteps * batch_per_device)                             # qmc.py:360
         return data, constants.pmean_if_pmap(pmove)                              # :361
 

@@ -214,6 +214,14 @@ int ds_mcmc_step(ds_system* sys, const void* params, void* x, void* lp, int64_t 
 int ds_mcmc_step_one_electron(ds_system* sys, const void* params, void* x, void* lp, int64_t B, int moves, int first_electron,
                               double width, uint64_t philox_seed, uint64_t philox_offset, const void* normals,
                               const void* uniforms, int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream);
+/* The same loop with the drift-biased importance-sampled move -- qmc.importance_update (qmc.py:83-150, symmetric branch) as
+ * make_mcmc_step(importance_sampling=...) drives it: per move  g1 = grad log|psi|(x);  x2 = wrap(x + width * N + width^2 *
+ * limdrift(g1));  (log|psi|, g2) at x2;  accept with the forward / reverse proposal densities (qmc.py:119-137).
+ * Noise as in ds_mcmc_step: Philox (normals of electron e: index w * N + e, uniform of walker w), or explicit
+ * `normals` (steps, B, 3N) / `uniforms` (steps, B).  Workspace: ds_mcmc_workspace_bytes(sys, B). */
+int ds_mcmc_step_importance(ds_system* sys, const void* params, void* x, void* lp, int64_t B, int steps, double width,
+                            uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms,
+                            int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream);
 /* the raw Philox block ds_mcmc_step uses for (seed, offset + step, index, stream_id): host evaluation for tests
  * (stream_id 0 / 1: normal deviates of electron `index`, 2: the uniform deviate of walker `index`). */
 void ds_philox_host(uint64_t seed, uint64_t offset, uint64_t step, uint64_t index, int stream_id, uint32_t out[4]);

@@ -400,3 +400,34 @@ def test_fused_one_electron_sampler(name):
     x1 = x0.clone(); lp1 = torch.empty(B, dtype=torch.float64, device='cuda')
     sysd.mcmc_step(dp, x1, lp1, 1, width, seed=3, offset=0, first_electron=0)
     np.testing.assert_allclose(x1[:, 3:].cpu().numpy(), x0[:, 3:].cpu().numpy(), atol=1e-12)
+
+
+@pytest.mark.parametrize('name', ['lih', 'bcc_li'])
+def test_fused_importance_sampler(name):
+    """`ds_mcmc_step_importance` (make_mcmc_step(importance_sampling=net.apply), qmc.py:83-150,324-325): with explicit noise it
+    equals `importance_update` called per move from Python (the path the reference-executed imp_* vectors pin) bit for bit;
+    with the in-kernel Philox stream a step is a pure function of its key."""
+    from deepsolid_amd import qmc
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    (slog,) = nets(cell, klist, net_kw, 'eval_slogdet')
+    cu = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device='cuda')
+    x0 = cu(fx['mcmc_x0'])
+    B, n3 = x0.shape
+    steps, width = 3, 0.12
+    rng = np.random.default_rng(8)
+    nz, un = rng.normal(size=(steps, B, n3)), rng.uniform(size=(steps, B))
+    step = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=steps, importance_sampling=slog.apply)
+    xf, pf = step(dp, x0, (cu(nz), cu(un)), width)
+    x, lp = x0.clone(), 2.0 * slog.apply(dp, x0)
+    nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for i in range(steps):
+        x, _, lp, nacc = qmc.importance_update(dp, slog.apply.value_and_grad, x, None, lp, nacc, cell.a, stddev=width,
+                                               normal=cu(nz[i]), uniform=cu(un[i]))
+    assert torch.equal(xf, x)
+    assert abs(float(pf) - float(nacc[0]) / (steps * B)) < 1e-15
+    xa, pa = step(dp, x0, 21, width)
+    xb, pb = step(dp, x0, 21, width)
+    xc, _ = step(dp, x0, 22, width)
+    assert torch.equal(xa, xb) and float(pa) == float(pb) and not torch.equal(xa, xc)
+    assert 0.0 < float(pa) <= 1.0
