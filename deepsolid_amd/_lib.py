@@ -64,6 +64,8 @@ SIGNATURES = {
                                            C.c_int, _VP, _VP, C.c_int64, _VP]),
     'ds_mcmc_step_importance': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int, C.c_double, C.c_uint64, C.c_uint64, _VP, _VP, C.c_int,
                                          _VP, _VP, C.c_int64, _VP]),
+    'ds_mcmc_step_asymmetric': (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, C.c_int, C.c_double, _VP, C.c_int, C.c_uint64, C.c_uint64, _VP, _VP,
+                                         C.c_int, _VP, _VP, C.c_int64, _VP]),
     'ds_philox_host': (None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]),
     'ds_energy_stats': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP]),
     'ds_debug_stage': (C.c_int64, [_VP, _VP, _VP, C.c_int64, C.c_char_p, _VP, C.c_int64, _VP, C.c_int64, _VP]),

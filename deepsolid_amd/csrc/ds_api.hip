@@ -1120,6 +1120,40 @@ int mcmc_importance_impl(ds_system* s, const void* params, void* x_, void* lp_, 
     return 0;
 }
 
+// Asymmetric all-electron proposal (mh_update with atoms=, qmc.py:197-215): step width per electron = width x harmonic mean of its
+// nuclear distances, forward / reverse proposal densities in the ratio -- the kernels of ds_mh_propose_ex / ds_mh_accept_ex (mode 1).
+template <typename T>
+int mcmc_asymmetric_impl(ds_system* s, const void* params, void* x_, void* lp_, int64_t B, int steps, double width, const void* atoms,
+                         int n_atoms, uint64_t seed, uint64_t offset, const void* normals_, const void* uniforms_, int lp_valid,
+                         void* n_accept, void* ws, int64_t ws_bytes, hipStream_t st) {
+    const ds::SysDev<T>& S = dev<T>(s);
+    const size_t head = mcmc_scratch_bytes(s, B);
+    if ((int64_t)head >= ws_bytes) return fail("workspace too small for ds_mcmc_step_asymmetric (see ds_mcmc_workspace_bytes)");
+    const size_t n3 = (size_t)B * 3 * S.N, ne = (size_t)B * S.N;
+    T* x = (T*)x_; T* lp = (T*)lp_;
+    T* X2 = (T*)ws; T* NZ = X2 + n3; T* LA2 = NZ + n3; T* UN = LA2 + B;
+    void* wsv = (char*)ws + head;
+    const int64_t wsv_bytes = ws_bytes - (int64_t)head;
+    const ds::PhiloxKey key{seed, offset};
+    const dim3 gn((unsigned)((std::max<size_t>(ne, (size_t)B) + 255) / 256)), blk(256);
+    if (!lp_valid) {
+        if (int rc = logpsi_impl<T>(s, params, x, B, LA2, nullptr, wsv, wsv_bytes, st)) return rc;
+        hipLaunchKernelGGL((ds::k_scale2<T>), dim3((unsigned)((B + 255) / 256)), blk, 0, st, LA2, (long)B, lp);
+    }
+    for (int i = 0; i < steps; ++i) {
+        const T* nz = normals_ ? (const T*)normals_ + (size_t)i * n3 : NZ;
+        const T* un = uniforms_ ? (const T*)uniforms_ + (size_t)i * B : UN;
+        if (!normals_) hipLaunchKernelGGL((ds::k_philox_noise<T>), gn, blk, 0, st, key, (unsigned long long)i, ne, (long)B, NZ, UN);
+        hipLaunchKernelGGL((ds::k_mh_propose_ex<T>), dim3((unsigned)((ne + 255) / 256)), blk, 0, st, S.sim_a, S.sim_ainv, 1, x, nz, (T)width,
+                           (const T*)atoms, n_atoms, ne, X2, (const T*)nullptr);                                     // :200-204
+        if (int rc = logpsi_impl<T>(s, params, X2, B, LA2, nullptr, wsv, wsv_bytes, st)) return rc;                  // :205
+        hipLaunchKernelGGL((ds::k_mh_accept_ex<T>), dim3((unsigned)B), dim3(64), 0, st, 1, x, lp, X2, LA2, un, (const T*)nullptr, (T)width,
+                           (const T*)atoms, (const T*)nullptr, n_atoms, S.N, (T*)n_accept, (const T*)nullptr);       // :208-222
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 
 int check_arch(const ds_system_desc* d) {
     if (d->dtype != 0 && d->dtype != 1) return fail("dtype must be 0 (f64) or 1 (f32)");
@@ -1425,6 +1459,20 @@ int ds_mcmc_step_one_electron(ds_system* s, const void* params, void* x, void* l
                                                   lp_valid, n_accept, ws, ws_bytes, st, first_electron)
                          : mcmc_step_impl<float>(s, params, x, lp, B, moves, width, philox_seed, philox_offset, normals, uniforms,
                                                  lp_valid, n_accept, ws, ws_bytes, st, first_electron);
+}
+
+int ds_mcmc_step_asymmetric(ds_system* s, const void* params, void* x, void* lp, int64_t B, int steps, double width, const void* atoms,
+                            int n_atoms, uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms,
+                            int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream) {
+    if (!s || !params || !x || !lp || !n_accept || !ws || !atoms) return fail("null argument");
+    if ((normals == nullptr) != (uniforms == nullptr)) return fail("normals and uniforms must be given together (or both NULL)");
+    if (steps < 0 || n_atoms < 1) return fail("steps must be >= 0 and n_atoms >= 1");
+    if (B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return s->dtype == 0 ? mcmc_asymmetric_impl<double>(s, params, x, lp, B, steps, width, atoms, n_atoms, philox_seed, philox_offset,
+                                                        normals, uniforms, lp_valid, n_accept, ws, ws_bytes, st)
+                         : mcmc_asymmetric_impl<float>(s, params, x, lp, B, steps, width, atoms, n_atoms, philox_seed, philox_offset,
+                                                       normals, uniforms, lp_valid, n_accept, ws, ws_bytes, st);
 }
 
 int ds_mcmc_step_importance(ds_system* s, const void* params, void* x, void* lp, int64_t B, int steps, double width,

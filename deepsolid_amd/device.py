@@ -474,12 +474,13 @@ class DeviceSystem:
                                             _ptr(n_accept), _ptr(scratch), _stream()), 'ds_mh_accept_ex')
 
     def mcmc_step(self, params, x, lp, steps, width, seed=0, offset=0, normals=None, uniforms=None, lp_valid=False,
-                  n_accept=None, first_electron=None, importance=False):
+                  n_accept=None, first_electron=None, importance=False, atoms=None):
         """`ds_mcmc_step`: `steps` all-electron Metropolis moves on x (B,3N) / lp (B,) IN PLACE, enqueued without a host
         synchronisation.  Noise from the in-kernel Philox stream (seed, offset) or replayed from `normals`
         (steps,B,3N) / `uniforms` (steps,B).  -> n_accept (1,) device tensor (incremented).
         `first_electron` = e: `ds_mcmc_step_one_electron` instead -- move i displaces electron (e + i) % N only
-        (explicit normals are then (steps,B,3)).  `importance=True`: `ds_mcmc_step_importance`, the drift-biased move."""
+        (explicit normals are then (steps,B,3)).  `importance=True`: `ds_mcmc_step_importance`, the drift-biased move.
+        `atoms` (A,3): `ds_mcmc_step_asymmetric`, step widths scaled by the harmonic mean of the nuclear distances."""
         x = self._check_x(x)
         B = x.shape[0]
         p = self.pack_params(params)
@@ -498,6 +499,13 @@ class DeviceSystem:
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if atoms is not None:
+            atoms = torch.as_tensor(atoms, dtype=self.dtype, device=self.device).reshape(-1, 3).contiguous()
+            _lib.check(self.lib.ds_mcmc_step_asymmetric(
+                self.handle, _ptr(p), _ptr(x), _ptr(lp), B, int(steps), float(width), _ptr(atoms), int(atoms.shape[0]),
+                int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _ptr(normals), _ptr(uniforms), int(bool(lp_valid)),
+                _ptr(n_accept), _ptr(self._ws), self._ws.numel(), _stream()), 'ds_mcmc_step_asymmetric')
+            return n_accept
         if importance:
             _lib.check(self.lib.ds_mcmc_step_importance(
                 self.handle, _ptr(p), _ptr(x), _ptr(lp), B, int(steps), float(width), int(seed) & (2 ** 64 - 1),

@@ -11,9 +11,10 @@ evaluated inside the kernels (replacing JAX's threefry, qmc.py:190-192,217-218).
 ``key`` is an int seed or a ``torch.Generator``; explicit noise ``(normals,
 uniforms)`` can be supplied instead for replay tests.  One-electron moves and
 the drift-biased importance-sampled move run the same way
-(``ds_mcmc_step_one_electron``, ``ds_mcmc_step_importance``).  The asymmetric
-``atoms=`` proposal draws from torch's generator and calls the propose / accept
-kernels per move.
+(``ds_mcmc_step_one_electron``, ``ds_mcmc_step_importance``), and so does the
+asymmetric ``atoms=`` proposal of ``mh_update`` (``ds_mcmc_step_asymmetric``).
+The per-move functions (``mh_update`` ... ``importance_update``) keep the
+reference's signatures and call the propose / accept kernels move by move.
 
 All three samplers of the reference are available: all-electron Metropolis
 (``mh_update``, the default), one-electron moves (``mh_one_electron_update``) and
@@ -161,16 +162,17 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
         inner_fun = mh_one_electron_update if one_electron_moves else mh_update                  # qmc.py:327-333
 
     system = batch_slog_network.system
-    # all three samplers run as ONE C-ABI call; the importance-sampled one when its drift comes from this system's own network
+    # every sampler runs as ONE C-ABI call; the importance-sampled one when its drift comes from this system's own network
     # (process.py:182 passes the same wavefunction) -- a foreign gradient function keeps the per-move path
-    fused = atoms is None and (importance_sampling is None or importance_sampling.system is system)
+    fused = (importance_sampling is None and not (one_electron_moves and atoms is not None)) or \
+            (atoms is None and importance_sampling.system is system)
     if fused:
         _check_latvec(latvec, system)
     gen_calls = {}                            # stateful torch.Generator keys: Philox offset advanced by `steps` per call
 
     def fused_step(params, data, key, width):
-        """The default sampler (`ds_mcmc_step`), the one-electron sampler (`ds_mcmc_step_one_electron`) or the importance-sampled
-        one (`ds_mcmc_step_importance`) as ONE C-ABI call:
+        """The default sampler (`ds_mcmc_step`), the one-electron sampler (`ds_mcmc_step_one_electron`), the importance-sampled
+        one (`ds_mcmc_step_importance`) or the asymmetric proposal (`ds_mcmc_step_asymmetric`) as ONE C-ABI call:
         proposal, wrap, log|psi|, accept/select for all moves are enqueued back to back; the noise is Philox evaluated inside the kernels.  `key`: an int is a
         pure key like a JAX PRNGKey (same key -> same moves; the caller passes a fresh one per iteration, the rank is
         folded in); a torch.Generator is stateful (its initial_seed keys the stream and every call advances the
@@ -183,7 +185,7 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
         imp = importance_sampling is not None
         if isinstance(key, (tuple, list)):
             nacc = system.mcmc_step(params, data, lp, nsteps, width, normals=key[0], uniforms=key[1], first_electron=first,
-                                    importance=imp)
+                                    importance=imp, atoms=atoms)
         else:
             if isinstance(key, torch.Generator):
                 seed = key.initial_seed()
@@ -191,7 +193,8 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
                 gen_calls[id(key)] = (key, off + nsteps)          # (holding the generator keeps its id unique)
             else:
                 seed, off = int(key) * max(1, constants.world_size()) + constants.rank(), 0
-            nacc = system.mcmc_step(params, data, lp, nsteps, width, seed=seed, offset=off, first_electron=first, importance=imp)
+            nacc = system.mcmc_step(params, data, lp, nsteps, width, seed=seed, offset=off, first_electron=first, importance=imp,
+                                    atoms=atoms)
         pmove = nacc[0] / (nsteps * batch_per_device)                             # qmc.py:360
         return data, constants.pmean_if_pmap(pmove)                              # :361
 

@@ -222,6 +222,12 @@ int ds_mcmc_step_one_electron(ds_system* sys, const void* params, void* x, void*
 int ds_mcmc_step_importance(ds_system* sys, const void* params, void* x, void* lp, int64_t B, int steps, double width,
                             uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms,
                             int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream);
+/* The same loop with the asymmetric proposal of mh_update(atoms=...) (qmc.py:197-215): the step width of an electron is
+ * width x the harmonic mean of its (non-periodic) distances to `atoms` (n_atoms, 3) [device, dtype]; the forward / reverse
+ * proposal densities enter the acceptance.  Noise as in ds_mcmc_step.  Workspace: ds_mcmc_workspace_bytes(sys, B). */
+int ds_mcmc_step_asymmetric(ds_system* sys, const void* params, void* x, void* lp, int64_t B, int steps, double width,
+                            const void* atoms, int n_atoms, uint64_t philox_seed, uint64_t philox_offset, const void* normals,
+                            const void* uniforms, int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream);
 /* the raw Philox block ds_mcmc_step uses for (seed, offset + step, index, stream_id): host evaluation for tests
  * (stream_id 0 / 1: normal deviates of electron `index`, 2: the uniform deviate of walker `index`). */
 void ds_philox_host(uint64_t seed, uint64_t offset, uint64_t step, uint64_t index, int stream_id, uint32_t out[4]);

@@ -431,3 +431,35 @@ def test_fused_importance_sampler(name):
     xc, _ = step(dp, x0, 22, width)
     assert torch.equal(xa, xb) and float(pa) == float(pb) and not torch.equal(xa, xc)
     assert 0.0 < float(pa) <= 1.0
+
+
+@pytest.mark.parametrize('name', ['lih', 'bcc_li'])
+def test_fused_asymmetric_sampler(name):
+    """`ds_mcmc_step_asymmetric` (make_mcmc_step(atoms=...), mh_update's asymmetric branch qmc.py:197-215): with explicit noise
+    it equals `mh_update(atoms=...)` called per move (the path the reference-executed mha_* vectors pin) bit for bit; Philox
+    keys are pure."""
+    from deepsolid_amd import qmc
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    (slog,) = nets(cell, klist, net_kw, 'eval_slogdet')
+    cu = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64, device='cuda')
+    x0 = cu(fx['mcmc_x0'])
+    B, n3 = x0.shape
+    atoms = np.asarray(cell.atom_coords(), dtype=np.float64)
+    steps, width = 3, 0.2
+    rng = np.random.default_rng(9)
+    nz, un = rng.normal(size=(steps, B, n3)), rng.uniform(size=(steps, B))
+    step = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=steps, atoms=atoms)
+    xf, pf = step(dp, x0, (cu(nz), cu(un)), width)
+    x, lp = x0.clone(), 2.0 * slog.apply(dp, x0)
+    nacc = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for i in range(steps):
+        x, _, lp, nacc = qmc.mh_update(dp, slog.apply, x, None, lp, nacc, cell.a, stddev=width, atoms=atoms,
+                                       normal=cu(nz[i]), uniform=cu(un[i]))
+    assert torch.equal(xf, x)
+    assert abs(float(pf) - float(nacc[0]) / (steps * B)) < 1e-15
+    xa, pa = step(dp, x0, 31, width)
+    xb, pb = step(dp, x0, 31, width)
+    xc, _ = step(dp, x0, 32, width)
+    assert torch.equal(xa, xb) and float(pa) == float(pb) and not torch.equal(xa, xc)
+    assert 0.0 < float(pa) <= 1.0
