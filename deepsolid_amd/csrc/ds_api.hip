@@ -140,6 +140,33 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
     size_t o_d27 = push(disp, 81), o_s27 = push(shift, 81);
     size_t o_g = push(d->gpoints, 3 * (size_t)d->n_g), o_gw = push(d->gweight, d->n_g);
     size_t o_ir = push(d->ion_exp_re, d->n_g), o_ii = push(d->ion_exp_im, d->n_g);
+    // integer coordinates of the G mesh in the reciprocal basis: n_j = G . a_j / 2 pi (ewaldsum.py:68-89 builds G from them);
+    // the phase tables of k_ewald are used when they are exact integers and N x (table length) fits comfortably in LDS
+    std::vector<double> gidx(3 * (size_t)d->n_g, 0.0);
+    int nmin[3] = {0, 0, 0}, nmax[3] = {0, 0, 0};
+    bool integral = d->n_g > 0 && !getenv("DS_EWALD_DIRECT");
+    for (int g = 0; g < d->n_g && integral; ++g)
+        for (int j = 0; j < 3; ++j) {
+            const double v = (d->gpoints[3 * g] * d->sim_a[3 * j] + d->gpoints[3 * g + 1] * d->sim_a[3 * j + 1] +
+                              d->gpoints[3 * g + 2] * d->sim_a[3 * j + 2]) / 6.283185307179586476925286766559;
+            const double r = std::nearbyint(v);
+            if (std::fabs(v - r) > 1e-6 || std::fabs(r) > 30000) { integral = false; break; }
+            gidx[3 * (size_t)g + j] = r;
+            if (g == 0 || r < nmin[j]) nmin[j] = (int)r;
+            if (g == 0 || r > nmax[j]) nmax[j] = (int)r;
+        }
+    int goff[3] = {0, 0, 0}, glen = 0;
+    if (integral) {
+        for (int j = 0; j < 3; ++j) { goff[j] = glen; glen += nmax[j] - nmin[j] + 1; }
+        if ((size_t)(d->n_up + d->n_dn) * glen * 2 * sizeof(T) > 64 * 1024) integral = false;
+    }
+    if (integral) {
+        for (int g = 0; g < d->n_g; ++g)
+            for (int j = 0; j < 3; ++j) gidx[3 * (size_t)g + j] += goff[j] - nmin[j];
+    } else glen = 0;
+    size_t o_gi = push(gidx.data(), integral ? gidx.size() : 0);
+    S.gidx = (const T*)o_gi; S.g_len = glen;
+    for (int j = 0; j < 3; ++j) { S.g_nmin[j] = nmin[j]; S.g_off[j] = goff[j]; }
     // offsets are turned into pointers after the upload
     S.prim_a = (const T*)o_pa; S.prim_ainv = (const T*)o_pi; S.sim_a = (const T*)o_sa; S.sim_ainv = (const T*)o_si;
     S.prim_AV = (const T*)o_pav; S.prim_BV = (const T*)o_pbv; S.sim_AV = (const T*)o_sav; S.sim_BV = (const T*)o_sbv;
@@ -180,7 +207,7 @@ template <typename T> void relocate(ds::SysDev<T>& S, const T* base) {
     auto fix = [&](const T*& p) { p = base + (size_t)p; };
     fix(S.prim_a); fix(S.prim_ainv); fix(S.sim_a); fix(S.sim_ainv); fix(S.prim_AV); fix(S.prim_BV); fix(S.sim_AV);
     fix(S.sim_BV); fix(S.atoms); fix(S.klist[0]); fix(S.klist[1]); fix(S.sim_atoms); fix(S.sim_charges); fix(S.disp27);
-    fix(S.shift27); fix(S.gpoints); fix(S.gweight); fix(S.ion_re); fix(S.ion_im);
+    fix(S.shift27); fix(S.gpoints); fix(S.gweight); fix(S.ion_re); fix(S.ion_im); fix(S.gidx);
 }
 
 template <typename T> ds::SysDev<T>& dev(ds_system* s);
@@ -760,7 +787,7 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
         T* tmp = (T*)ws;
         for (int64_t b0 = 0; b0 < B; b0 += chunk) {
             const int64_t Bc = std::min(chunk, B - b0);
-            size_t sh = (size_t)(3 * S.N + 512) * sizeof(T);
+            size_t sh = ds::ewald_lds_bytes(S);
             ProfScope ps(s, DS_PROF_EWALD, st);
             hipLaunchKernelGGL((ds::k_ewald<T>), dim3((unsigned)Bc), dim3(256), sh, st, S, (const T*)x + b0 * 3 * S.N, tmp);
             hipLaunchKernelGGL((ds::k_sum3<T>), dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, tmp, Bc, (T*)out_ewald + b0);
@@ -1317,10 +1344,10 @@ int ds_ewald(ds_system* s, const void* x, int64_t B, void* out, void* stream) {
     if (B <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (s->dtype == 0) {
-        size_t sh = (size_t)(3 * s->sd.N + 512) * sizeof(double);
+        size_t sh = ds::ewald_lds_bytes(s->sd);
         hipLaunchKernelGGL((ds::k_ewald<double>), dim3((unsigned)B), dim3(256), sh, st, s->sd, (const double*)x, (double*)out);
     } else {
-        size_t sh = (size_t)(3 * s->sf.N + 512) * sizeof(float);
+        size_t sh = ds::ewald_lds_bytes(s->sf);
         hipLaunchKernelGGL((ds::k_ewald<float>), dim3((unsigned)B), dim3(256), sh, st, s->sf, (const float*)x, (float*)out);
     }
     HIP_OK(hipGetLastError());

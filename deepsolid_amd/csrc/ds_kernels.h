@@ -45,7 +45,15 @@ template <typename T> struct SysDev {
     int As, NG, dist_mode;
     const T *sim_atoms, *sim_charges, *disp27, *shift27, *gpoints, *gweight, *ion_re, *ion_im;
     T alpha, ee_const, ei_const, ii_total;
+    // G = 2 pi (n1, n2, n3) . recvec: gidx (NG,3) = the three table positions of a G point (n_j - nmin_j + g_off[j], stored as T),
+    // g_len = table entries per electron (0: no tables, direct sincos per (G, electron))
+    const T* gidx;
+    int g_nmin[3], g_off[3], g_len;
 };
+// dynamic LDS of k_ewald: walker coordinates + two reduction arrays + the per-electron phase tables
+template <typename T> inline size_t ewald_lds_bytes(const SysDev<T>& S) {
+    return (size_t)(3 * S.N + 512 + 2 * (size_t)S.N * S.g_len) * sizeof(T);
+}
 
 __device__ __forceinline__ int spin_of(int i, int n_up) { return i < n_up ? 0 : 1; }
 
@@ -918,7 +926,37 @@ __global__ void __launch_bounds__(256) k_ewald(SysDev<T> S, const T* __restrict_
         }
         if (it < n_ei) ei += q * acc; else ee += acc;
     }
-    // reciprocal space
+    // reciprocal space (ewaldsum.py:176-182): sum_G w_G |sum_e e^{iG.r_e}|^2 and the electron-ion term
+    if (S.g_len > 0) {
+        // every G is an integer combination of the reciprocal vectors, so e^{iG.r} = E_1[n1] E_2[n2] E_3[n3] with
+        // E_j[n] = exp(i n theta_j), theta_j = 2 pi frac_j(r): N * g_len sincos per walker instead of N * NG
+        T* tab = red + 512;                      // [N][g_len][re, im]
+        const int L = S.g_len;
+        for (int idx = tid; idx < N * L; idx += 256) {
+            const int i = idx / L, t = idx - i * L;
+            const int j = t >= S.g_off[2] ? 2 : (t >= S.g_off[1] ? 1 : 0);
+            const T nn = (T)(S.g_nmin[j] + (t - S.g_off[j]));
+            const T frac = xs[3 * i] * S.sim_ainv[j] + xs[3 * i + 1] * S.sim_ainv[3 + j] + xs[3 * i + 2] * S.sim_ainv[6 + j];
+            T sn, cs;
+            ds_sincos(nn * (T(6.283185307179586476925286766559) * frac), &sn, &cs);
+            tab[2 * idx] = cs; tab[2 * idx + 1] = sn;
+        }
+        __syncthreads();
+        for (int g = tid; g < S.NG; g += 256) {
+            const int t0 = (int)S.gidx[3 * g], t1 = (int)S.gidx[3 * g + 1], t2 = (int)S.gidx[3 * g + 2];
+            T ss = 0, sc = 0;
+            for (int i = 0; i < N; ++i) {
+                const T* ti = tab + 2 * (size_t)i * L;
+                const T ar = ti[2 * t0], ai = ti[2 * t0 + 1], br = ti[2 * t1], bi = ti[2 * t1 + 1], cr = ti[2 * t2], ci = ti[2 * t2 + 1];
+                const T pr = ar * br - ai * bi, pi = ar * bi + ai * br;
+                sc += pr * cr - pi * ci;
+                ss += pr * ci + pi * cr;
+            }
+            const T wg = S.gweight[g];
+            ee += wg * (ss * ss + sc * sc);
+            ei += 2 * wg * (-S.ion_re[g] * sc - S.ion_im[g] * ss);
+        }
+    } else
     for (int g = tid; g < S.NG; g += 256) {
         const T g0 = S.gpoints[3 * g], g1 = S.gpoints[3 * g + 1], g2 = S.gpoints[3 * g + 2];
         T ss = 0, sc = 0;
