@@ -64,6 +64,21 @@ def test_ewald_vs_reference_vectors(name):
     np.testing.assert_allclose([float(v) for v in e1], fx['ewald'][0], atol=5e-10)
 
 
+@pytest.mark.parametrize('name', ['h2', 'bcc_li', 'graphene'])
+def test_ewald_direct_sum_fallback_vs_reference_vectors(name, monkeypatch):
+    """The reciprocal sum has two device paths (ds_api.hip: phase tables when every G is an integer combination of the
+    reciprocal vectors and the tables fit the LDS, direct sincos otherwise).  DS_EWALD_DIRECT is read at system creation:
+    the fallback must reproduce the reference-executed energies too, and agree with the table path to rounding."""
+    fx, cell, klist, net_kw, params = load_case(name)
+    from deepsolid_amd.ewaldsum import EwaldSum
+    x = torch.as_tensor(fx['x'], device='cuda')
+    tab = torch.stack(EwaldSum(cell).energy(x), -1).cpu().numpy()
+    monkeypatch.setenv('DS_EWALD_DIRECT', '1')
+    direct = torch.stack(EwaldSum(cell).energy(x), -1).cpu().numpy()
+    np.testing.assert_allclose(direct, fx['ewald'], atol=5e-10)
+    np.testing.assert_allclose(direct, tab, atol=1e-10)
+
+
 @pytest.mark.parametrize('name', ['h2', 'lih', 'bcc_li', 'graphene'])
 def test_wrap_vs_reference_vectors(name):
     fx, cell, _, _, _ = load_case(name)
