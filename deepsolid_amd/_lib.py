@@ -71,6 +71,8 @@ SIGNATURES = {
     'ds_debug_stage': (C.c_int64, [_VP, _VP, _VP, C.c_int64, C.c_char_p, _VP, C.c_int64, _VP, C.c_int64, _VP]),
     'ds_profile_enable': (C.c_int, [_VP, C.c_int]),
     'ds_profile_read': (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'ds_profile_read_clock': (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'ds_debug_timeline': (C.c_int, [_VP, C.POINTER(C.c_uint64), C.c_int]),
     'ds_calib_copy': (C.c_int, [_VP, _VP, C.c_int64, _VP]),
     'ds_mfma_f64_peak': (C.c_int64, [C.c_int64, C.c_int, C.c_int, _VP, _VP]),
 }

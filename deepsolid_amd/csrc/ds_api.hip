@@ -13,6 +13,7 @@
 
 #include "../../include/deepsolid_hip.h"
 #include "ds_grad.h"
+#include "ds_layer.h"
 #include "ds_mcmc.h"
 
 namespace {
@@ -48,6 +49,7 @@ void inv3(const double* a, double* o) {
 // per-walker workspace carve, in elements
 struct WsLayout {
     size_t G, MEAN, ZB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
+    size_t M2V = 0;                                        // partner means of the pair stream as 5-jets (ds_layer.h)
     size_t PARTM = 0;                                      // value chain: per-tile segment sums of the pair layer (k_two_layer)
     size_t mout_off[2], minv_off[2], dets_off[2], tr_off[2];
     size_t per_walker;                                     // total elements per walker
@@ -75,6 +77,11 @@ struct ds_system {
     bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
+    int lg_tile = 42;                 // DS_LG_TILE: 10 * (electrons per pass) + waves per SIMD of k_layer_group
+    int lg_ring = 2;                  // DS_LG_RING: operand ring depth of k_layer_group (2 or 4)
+    int lg_dbg = 0;                   // DS_LG_DBG (timing experiments, wrong results)
+    size_t lg_pad_lds = 0;            // DS_LG_PAD_LDS (experiment): extra dynamic LDS per workgroup of k_layer_group
+    bool layer_groups = true;         // electron-group layer kernels (ds_layer.h); DS_LAYER_GROUPS=0 selects the per-electron k_jet_gemm path
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
@@ -82,6 +89,8 @@ struct ds_system {
     int prof_only = -1;               // >= 0: record events for this kernel kind only (keeps the timed region undisturbed)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[DS_PROF_KINDS];
     std::vector<hipEvent_t> prof_pool;
+    unsigned long long* clk_dev = nullptr;   // [2] cycles / ticks accumulated by the hidden-layer kernel while profiling (in-kernel clock probe)
+    bool prof_failed = false;         // an event could not be created / recorded: ds_profile_read reports it
 };
 
 namespace {
@@ -91,13 +100,26 @@ struct ProfScope {
     ds_system* s; int kind; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
     static hipEvent_t get(ds_system* s) {
         if (!s->prof_pool.empty()) { hipEvent_t e = s->prof_pool.back(); s->prof_pool.pop_back(); return e; }
-        hipEvent_t e; (void)hipEventCreate(&e); return e;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { s->prof_failed = true; return nullptr; }
+        return e;
     }
     ProfScope(ds_system* s_, int kind_, hipStream_t st_) : s(s_), kind(kind_), st(st_) {
-        if (s->prof_on && (s->prof_only < 0 || s->prof_only == kind)) { e0 = get(s); e1 = get(s); (void)hipEventRecord(e0, st); }
+        if (s->prof_on && (s->prof_only < 0 || s->prof_only == kind)) {
+            e0 = get(s); e1 = get(s);
+            if (!e0 || !e1 || hipEventRecord(e0, st) != hipSuccess) { s->prof_failed = true; recycle(); }
+        }
+    }
+    void recycle() {
+        if (e0) s->prof_pool.push_back(e0);
+        if (e1) s->prof_pool.push_back(e1);
+        e0 = e1 = nullptr;
     }
     ~ProfScope() {
-        if (e0) { (void)hipEventRecord(e1, st); s->prof_ev[kind].push_back({e0, e1}); }
+        if (e0) {
+            if (hipEventRecord(e1, st) == hipSuccess) s->prof_ev[kind].push_back({e0, e1});
+            else { s->prof_failed = true; recycle(); }
+        }
     }
 };
 
@@ -165,6 +187,9 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
             for (int j = 0; j < 3; ++j) gidx[3 * (size_t)g + j] += goff[j] - nmin[j];
     } else glen = 0;
     size_t o_gi = push(gidx.data(), integral ? gidx.size() : 0);
+    const double zero_word[4] = {0, 0, 0, 0};
+    size_t o_zero = push(zero_word, 4);
+    S.zero = (const T*)o_zero;
     S.gidx = (const T*)o_gi; S.g_len = glen;
     for (int j = 0; j < 3; ++j) { S.g_nmin[j] = nmin[j]; S.g_off[j] = goff[j]; }
     // offsets are turned into pointers after the upload
@@ -198,6 +223,15 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
     S.nparam[0] = S.norb[0] * d->n_det; S.nparam[1] = d->n_dn ? S.norb[1] * d->n_det : 0;
     S.nparam_max = std::max(S.nparam[0], S.nparam[1]);
     S.ocols[0] = rup(2 * S.nparam[0], 64); S.ocols[1] = rup(2 * S.nparam[1], 64);
+    // electron groups of the layer kernels: consecutive electrons of one spin, at most LG_GE each
+    S.n_groups = 0;
+    for (int sp = 0; sp < S.nch; ++sp) {
+        const int i0 = sp == 0 ? 0 : d->n_up, ns = sp == 0 ? d->n_up : d->n_dn;
+        for (int e = 0; e < ns && S.n_groups < DS_MAXG; e += ds::LG_GE) {
+            S.grp_e0[S.n_groups] = i0 + e; S.grp_n[S.n_groups] = std::min(ds::LG_GE, ns - e); S.grp_sp[S.n_groups] = sp;
+            ++S.n_groups;
+        }
+    }
     S.As = d->n_atoms_sim; S.NG = d->n_g; S.dist_mode = d->dist_mode;
     S.alpha = (T)d->ewald_alpha; S.ee_const = (T)d->ee_const; S.ei_const = (T)d->ei_const; S.ii_total = (T)d->ii_total;
     (void)s;
@@ -207,7 +241,7 @@ template <typename T> void relocate(ds::SysDev<T>& S, const T* base) {
     auto fix = [&](const T*& p) { p = base + (size_t)p; };
     fix(S.prim_a); fix(S.prim_ainv); fix(S.sim_a); fix(S.sim_ainv); fix(S.prim_AV); fix(S.prim_BV); fix(S.sim_AV);
     fix(S.sim_BV); fix(S.atoms); fix(S.klist[0]); fix(S.klist[1]); fix(S.sim_atoms); fix(S.sim_charges); fix(S.disp27);
-    fix(S.shift27); fix(S.gpoints); fix(S.gweight); fix(S.ion_re); fix(S.ion_im); fix(S.gidx);
+    fix(S.shift27); fix(S.gpoints); fix(S.gweight); fix(S.ion_re); fix(S.ion_im); fix(S.gidx); fix(S.zero);
 }
 
 template <typename T> ds::SysDev<T>& dev(ds_system* s);
@@ -247,7 +281,8 @@ void build_layouts(ds_system* s) {
     int h1max = 0, h2max = 0;
     for (int l = 0; l <= S.n_layers; ++l) { h1max = std::max(h1max, S.h1[l]); h2max = std::max(h2max, S.h2[l]); }
     w.G = (size_t)S.N * S.ldk * S.P;
-    w.MEAN = (size_t)S.nch * h1max * S.P;
+    w.MEAN = (size_t)S.n_groups * h1max * S.P;       // (>= nch: also holds the per-group partial spin means of a layer's output)
+    w.M2V = (size_t)rup(S.N * S.nch * h2max * 5, 16);
     w.ZB = (size_t)std::max(h1max, std::max(S.ocols[0], S.ocols[1])) * S.P;   // shared spin-mean term S of one layer / orbital head
     for (int c = 0; c < S.nch; ++c)                  // ... or the orbital GEMM output of one spin
         w.ZB = std::max(w.ZB, (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * S.P);
@@ -263,7 +298,7 @@ void build_layouts(ds_system* s) {
         tr += (size_t)S.K * 2 * S.P;
     }
     w.MOUT = mo; w.MINV = rup((int)mi, 16); w.DETS = rup((int)de, 16); w.TR = tr;
-    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR;
+    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR + w.M2V;
     // value chain: the slot axis carries PV walkers (ds_value.h)
     WsLayout& v = s->wsv;
     const size_t PV = ds::PV;
@@ -280,14 +315,14 @@ void build_layouts(ds_system* s) {
         v.mout_off[c] = mo;
         mo += (size_t)S.K * n * n * 2 * PV;
     }
-    v.MOUT = mo; v.MINV = 0; v.TR = 0;
+    v.MOUT = mo; v.MINV = 0; v.TR = 0; v.M2V = 0;
     v.DETS = w.DETS * PV;             // DETS stays per walker
     v.PARTM = (size_t)(PV / 5) * h2max * 5 * (S.NP / 16) * ds::PM_SLOTS;
     v.per_walker = 2 * v.G + 2 * v.MEAN + v.ZB + 2 * v.H2 + v.Q + v.MOUT + v.DETS + v.PARTM;
 }
 
 template <typename T> struct Carve {
-    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR;
+    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR, *M2V;
 };
 template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     const WsLayout& w = s->ws;
@@ -302,6 +337,7 @@ template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     c.MINV = p; p += w.MINV * Bc;
     c.DETS = p; p += w.DETS * Bc;
     c.TR = p; p += w.TR * Bc;
+    c.M2V = p; p += w.M2V * Bc;
     return c;
 }
 
@@ -378,10 +414,19 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     if (stop == STOP_H2_0) return copy_out(dr, c.H2[0], (size_t)S.h2[0] * 5 * S.NP * Bc, st);
     if (stop == STOP_Q) return copy_out(dr, c.Q, L.Q * Bc, st);
     int gi = 0, hi = 0, mi = 0;       // current G / H2 / MEAN buffer
+    bool have_meanp = false;          // MEAN[1] holds the partial spin means of the current G (left by a grouped layer)
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
+        if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
+        // electron-group layer kernel (ds_layer.h): pair-mean rows generated in the operand load, spin means of the output
+        // formed in the epilogue.  The per-electron path below stays for DS_LAYER_GROUPS=0 and for the stage dumps.
+        const bool grouped = s->layer_groups && K2 % 4 == 0 && Kh % 4 == 0;
+        if (grouped) {
+            ProfScope ps(s, DS_PROF_M2_EXPAND, st);
+            hipLaunchKernelGGL((ds::k_m2_means<T>), dim3(S.N, (unsigned)Bc), dim3(256), 0, st, S, c.H2[hi], K2, c.M2V, L.M2V);
+        }
         // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
-        {
+        if (!grouped || stop == STOP_G0 + l) {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
             hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
                                c.H2[hi], K2, c.G[gi], Kh);
@@ -402,10 +447,10 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
 #undef DS_TWO
         }
         // one-electron stream layer: GEMM over the N electron tiles + the shared spin-mean tile, then epilogue
-        if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
+        const int hin = hi;                                // the layer reads the pair stream of its own level (hi flips below)
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
         const bool res = Kh == Nout;
-        if (res && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
+        if (!grouped && res && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             dim3 block; unsigned gz;
@@ -419,7 +464,19 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
                                        (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[0], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
                                        c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
-                else {
+                else if (have_meanp) {
+                    // hidden layer after a grouped layer: the spin means of its input came out of that layer's epilogue
+                    // (MEANP, one partial mean per electron group); several groups per spin are folded first
+                    const T* mean = c.MEAN[1];
+                    if (S.n_groups > S.nch) {
+                        hipLaunchKernelGGL((ds::k_group_fold<T>), dim3((unsigned)((S.nch * Kh * S.P + 1023) / 1024), (unsigned)Bc), dim3(256), 0, st, S,
+                                           c.MEAN[1], L.MEAN, Kh, c.MEAN[0], L.MEAN);
+                        mean = c.MEAN[0];
+                    }
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
+                                       (size_t)0, (size_t)0, (const T*)nullptr, 0, mean, L.MEAN, blk(s->i_wsh[l]), Ksh, 0,
+                                       c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                } else {
                     // (its own geometry: as many waves per workgroup as possible, every workgroup re-forms the spin means)
                     dim3 sblock; unsigned sgz;
                     gemm_geom(Nout, NB, &sblock, &sgz);
@@ -427,7 +484,28 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                                        c.G[gi], blk(s->i_wsh[l]), Kh, c.ZB, Nout, S.P, blk(s->i_b[l]), 0);
                 }
             }
-            {
+            if (grouped) {
+                ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
+                dim3 gblock; unsigned ggz;
+                gemm_geom(Nout, 4, &gblock, &ggz);
+                ds::LayerArgs<T> la{c.G[gi], c.G[gi ^ 1], gws, gts, blk(s->i_wloc[l]), Kh, K2, Nout, c.ZB, c.H2[hin], (size_t)K2 * 5 * S.NP,
+                                    c.M2V, L.M2V, c.MEAN[1], L.MEAN, S.zero,
+                                    (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) ? s->clk_dev : nullptr, s->lg_dbg};
+                const size_t lds = ds::layer_group_lds_bytes<T>(gblock.x) + s->lg_pad_lds;
+                const dim3 ggrid(S.n_groups * ggz, (unsigned)Bc, 1);
+                const int pipe = (s->lg_ring == 4 && Kh % 16 == 0 && K2 % 16 == 0) ? 4 : ((Kh % 8 == 0 && K2 % 8 == 0) ? 2 : 0);
+#define DS_LG(RESV, PIPEV, STV, WPSV) hipLaunchKernelGGL((ds::k_layer_group<T, RESV, PIPEV, STV, WPSV>), ggrid, gblock, lds, st, S, la)
+                // (DS_LG_TILE = 10 * ST + WPS selects the experimental tile shapes of the residual hidden layers)
+                if (res && pipe == 4 && s->lg_tile == 22) DS_LG(true, 4, 2, 2);
+                else if (res && pipe >= 2 && s->lg_tile == 23) DS_LG(true, 2, 2, 3);
+                else if (res && pipe >= 2 && s->lg_tile == 32) DS_LG(true, 2, 3, 2);
+                else if (res && pipe == 4) DS_LG(true, 4, 4, 2);
+                else if (res && pipe == 2) DS_LG(true, 2, 4, 2);
+                else if (res) DS_LG(true, 0, 4, 2);
+                else if (pipe >= 2) DS_LG(false, 2, 4, 2);
+                else DS_LG(false, 0, 4, 2);
+#undef DS_LG
+            } else {
                 // ... then the N electron tiles with the fused epilogue
                 ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
                 if (res)
@@ -440,6 +518,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                                        (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
             }
         });
+        have_meanp = grouped;
         if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
         gi ^= 1;
         if (l < S.n_double) {
@@ -1188,10 +1267,25 @@ int check_arch(const ds_system_desc* d) {
     if (d->distance_type == 1 && d->envelope_type != 0) return fail("the 'tri' features support the isotropic envelope only");
     if (d->envelope_type < 0 || d->envelope_type > 2) return fail("unknown envelope_type");
     if (d->n_up < 1) return fail("n_up must be >= 1");
-    if (d->n_dn > d->n_up) return fail("n_dn > n_up is not supported");
+    if (d->n_dn < 0) return fail("n_dn must be >= 0");
     if (d->n_layers < 1 || d->n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
     if (d->n_det < 1 || d->n_det > 32) return fail("n_det must be in 1..32");
     if (d->n_sym < 3 || d->n_sym > DS_MAX_SYM) return fail("bad n_sym");
+    // every shape limit of the kernels is checked HERE, so that a handle that was created never fails at its first launch
+    const int N = d->n_up + d->n_dn, tiles = (3 * N + 2 + 15) / 16, nmat = d->full_det ? N : std::max(d->n_up, d->n_dn);
+    if (nmat > 64) return fail("determinant matrices larger than 64 x 64 are not supported (n = %d): the trace kernels keep a matrix row per lane group", nmat);
+    if (!((tiles >= 1 && tiles <= 10) || tiles == 19))
+        return fail("no kernel instance for %d jet-slot tiles (N = %d electrons): supported are N <= 52 and 96 <= N <= 100", tiles, N);
+    const int n_double = d->use_last_layer ? d->n_layers : d->n_layers - 1;
+    const int nch = d->n_dn > 0 ? 2 : 1;
+    for (int l = 0; l < d->n_layers; ++l) {
+        if (d->hidden_single[l] % 64 || d->hidden_single[l] < 64 || d->hidden_single[l] > 1024)
+            return fail("hidden_single must be a multiple of 64 in 64..1024 (layer %d: %d)", l, d->hidden_single[l]);
+        if (l < n_double && d->hidden_double[l] != 16 && d->hidden_double[l] != 32)
+            return fail("hidden_double must be 16 or 32 (layer %d: %d)", l, d->hidden_double[l]);
+    }
+    const int k_orb = d->hidden_single[d->n_layers - 1] + (d->use_last_layer ? nch * d->hidden_double[d->n_layers - 1] : 0);
+    if (k_orb % 16) return fail("orbital head with K = %d input rows: the GEMM's operand ring needs K %% 16 == 0", k_orb);
     return 0;
 }
 
@@ -1225,11 +1319,21 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     relocate<double>(s->sd, (const double*)s->blob64);
     relocate<float>(s->sf, (const float*)s->blob32);
     build_layouts(s);
+    if (hipMalloc((void**)&s->clk_dev, 1024 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(s->clk_dev, 0, 1024 * sizeof(unsigned long long)) != hipSuccess) {
+        ds_system_destroy(s);
+        return fail("hipMalloc of the clock-probe counters failed");
+    }
     // environment switches are read here, once; the launch paths never call getenv
     if (const char* e = getenv("DS_STREAMS")) s->n_streams = atoi(e) == 2 ? 2 : 1;
     s->det_valu = getenv("DS_DET_VALU") != nullptr;
     s->det_half_slots = getenv("DS_DET_HALF_SLOTS") != nullptr;
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
+    if (const char* e = getenv("DS_LAYER_GROUPS")) s->layer_groups = atoi(e) != 0;
+    if (const char* e = getenv("DS_LG_PAD_LDS")) s->lg_pad_lds = (size_t)atol(e);
+    if (const char* e = getenv("DS_LG_DBG")) s->lg_dbg = atoi(e);
+    if (const char* e = getenv("DS_LG_RING")) s->lg_ring = atoi(e);
+    if (const char* e = getenv("DS_LG_TILE")) s->lg_tile = atoi(e);
     if (s->n_streams == 2) {
         bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
         // DS_CUMASK=1: each side stream owns one half of the CU mask bits (experiment: chunks at different phases on disjoint CUs)
@@ -1262,6 +1366,7 @@ void ds_system_destroy(ds_system* s) {
         if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->clk_dev) (void)hipFree(s->clk_dev);
     if (s->blob64) (void)hipFree(s->blob64);
     if (s->blob32) (void)hipFree(s->blob32);
     delete s;
@@ -1581,11 +1686,30 @@ int ds_profile_enable(ds_system* s, int on) {
     }
     s->prof_on = on != 0;
     s->prof_only = on >= 2 ? on - 2 : -1;      // on = 2 + kind: that kernel kind only
+    if (on) HIP_OK(hipMemset(s->clk_dev, 0, 1024 * sizeof(unsigned long long)));
+    return 0;
+}
+
+int ds_debug_timeline(ds_system* s, uint64_t* out, int n) {
+    if (!s || !out || n < 0 || n > 1022) return fail("bad argument");
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out, s->clk_dev + 2, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ds_profile_read_clock(ds_system* s, double* shader_cycles, double* ref_ticks) {
+    if (!s || !shader_cycles || !ref_ticks) return fail("null argument");
+    unsigned long long h[2] = {0, 0};
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(h, s->clk_dev, sizeof h, hipMemcpyDeviceToHost));
+    *shader_cycles = (double)h[0];
+    *ref_ticks = (double)h[1];
     return 0;
 }
 
 int ds_profile_read(ds_system* s, double* ms_total, int64_t* launches) {
     if (!s || !ms_total || !launches) return fail("null argument");
+    if (s->prof_failed) { s->prof_failed = false; return fail("profiling: a HIP event could not be created or recorded; the timings are incomplete"); }
     for (int k = 0; k < DS_PROF_KINDS; ++k) {
         double tot = 0;
         for (auto& p : s->prof_ev[k]) {

@@ -88,25 +88,23 @@ template <int N, typename T> __device__ __forceinline__ T row16_bcast_dyn(T v, i
 // one range reduction 2|x| = k ln2 + r, |r| <= ln2 / 2, and the degree-14 Taylor polynomial of expm1(r); no cancellation
 // anywhere.  Measured against long-double tanhl over 2e7 arguments in [-20, 20] and 1e-13 .. 1e13: max relative error
 // 3.5e-16 (the host libm: 3.0e-16).  ~45 instructions.
+// (the coefficients come from constant memory through scalar loads: as literals every one of them would occupy a VGPR pair
+//  that the compiler hoists out of the surrounding loops -- ~36 registers held for the whole kernel)
+__device__ __constant__ double DS_TANH_C[16] = {
+    1.0 / 87178291200.0, 1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+    1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 1.4426950408889634074, -6.93147180369123816490e-01,
+    -1.90821492927058770002e-10, 80.0};
 __device__ __forceinline__ double ds_tanh(double x) {
+    const double* C = DS_TANH_C;
     const double ax = fabs(x);
     double t = ax + ax;
-    t = t > 80.0 ? 80.0 : t;                                      // tanh is 1 to the last bit beyond; keeps inf finite, NaN stays NaN
-    const double kf = rint(t * 1.4426950408889634074);
-    double r = fma(kf, -6.93147180369123816490e-01, t);
-    r = fma(kf, -1.90821492927058770002e-10, r);
-    double q = 1.0 / 87178291200.0;
-    q = fma(q, r, 1.0 / 6227020800.0);
-    q = fma(q, r, 1.0 / 479001600.0);
-    q = fma(q, r, 1.0 / 39916800.0);
-    q = fma(q, r, 1.0 / 3628800.0);
-    q = fma(q, r, 1.0 / 362880.0);
-    q = fma(q, r, 1.0 / 40320.0);
-    q = fma(q, r, 1.0 / 5040.0);
-    q = fma(q, r, 1.0 / 720.0);
-    q = fma(q, r, 1.0 / 120.0);
-    q = fma(q, r, 1.0 / 24.0);
-    q = fma(q, r, 1.0 / 6.0);
+    t = t > C[15] ? C[15] : t;                                    // tanh is 1 to the last bit beyond; keeps inf finite, NaN stays NaN
+    const double kf = rint(t * C[12]);
+    double r = fma(kf, C[13], t);
+    r = fma(kf, C[14], r);
+    double q = C[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) q = fma(q, r, C[i]);
     q = fma(q, r, 0.5);
     const double p = fma(r * r, q, r);                           // expm1(r)
     int k = (int)kf;

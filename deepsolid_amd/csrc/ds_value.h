@@ -220,6 +220,10 @@ __global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __rest
             const T ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
+        // every remaining candidate NaN (m2 > best is false for all of them): take the lowest unused row, so that the NaN
+        // becomes the pivot and log|det| comes out NaN like slogdet / k_det_inverse -- a move into such a configuration is
+        // then rejected (lp2 - lp1 > log u is false) instead of being accepted with a finite garbage value
+        if (bi >= NC) bi = __ffs((int)(~used)) - 1;
         const int owner = qbase | (bi / R), orr = bi % R;
         if (__popc(~used & ((1u << bi) - 1u)) & 1) ph = Cx<T>(-ph.re, -ph.im);      // unused rows skipped: parity of the order
         used |= 1u << bi;

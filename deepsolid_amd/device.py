@@ -544,6 +544,13 @@ class DeviceSystem:
         _lib.check(self.lib.ds_profile_read(self.handle, ms, cnt), 'ds_profile_read')
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(_lib.PROF_KINDS)}
 
+    def profile_clock(self):
+        """In-kernel clock probe of the hidden-layer kernel since profile(True): -> (shader cycles, 100 MHz reference ticks,
+        GHz) summed over its workgroups; GHz is None when the probe did not run."""
+        cyc, ticks = C.c_double(0), C.c_double(0)
+        _lib.check(self.lib.ds_profile_read_clock(self.handle, C.byref(cyc), C.byref(ticks)), 'ds_profile_read_clock')
+        return cyc.value, ticks.value, (cyc.value / ticks.value * 0.1 if ticks.value > 0 else None)
+
     def debug_stage(self, params, x, stage, n_elems):
         x = self._check_x(x)
         p = self.pack_params(params)

@@ -41,14 +41,18 @@ class Writer:
         self._file.close()
 
 
-def _rank_generator(key, device):
+def _rank_generator(key, device, t_init=0):
     """Per-rank noise stream: the reference folds the host index into the key and splits it per device
     (process.py:104, constants.py:54-57); here one process drives one GPU, so the rank is folded into the seed.
-    Walkers must be initialised per rank as well (`init_guess.init_electrons` takes its own key)."""
+    Walkers must be initialised per rank as well (`init_guess.init_electrons` takes its own key).
+    `t_init` (the first iteration of a resumed run) is folded in as well, so that a run restarted from a checkpoint with
+    the same key does not replay the noise of iterations 0..k of the first run (the reference draws a fresh, time-based
+    key on every start, process.py:99-104)."""
     if isinstance(key, torch.Generator):
         return key
     from . import constants
     seed = int(key) * max(1, constants.world_size()) + constants.rank()
+    seed = (seed + 0x9E3779B97F4A7C15 * int(t_init)) % (1 << 63)
     return torch.Generator(device=device).manual_seed(seed)
 
 
@@ -108,13 +112,17 @@ def learning_rate_schedule(rate=5e-2, decay=1.0, delay=10000.0):
 def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations, key=0, move_width=0.02, mcmc_steps=10,
                  burn_in=100, adapt_frequency=100, learning_rate=None, clip_local_energy=5.0, clip_type='real',
                  save_path=None, save_every=None, stats_file_name='train_stats', laplacian_mode='for',
-                 partition_number=3, t_init=0, opt_state=None):
+                 partition_number=3, t_init=0, opt_state=None, check_nan=True):
     """The `optimizer='adam'` branch of the reference driver (process.py:204-219, 256-383): burn-in, then per iteration
     ``mcmc_step -> value_and_grad(total_energy) -> gradient pmean -> Adam -> CSV row -> width adaptation``, with
     checkpoints in the reference's layout (`deepsolid_amd.checkpoint.save`) every `save_every` iterations.
-    `params` is updated in place.  Returns (data, params, opt_state, mcmc_width, rows)."""
+    `params` is updated in place.  Returns (data, params, opt_state, mcmc_width, rows).
+    `check_nan` (cfg.debug.check_nan, process.py:303-318; on by default here: Adam updates in place, one NaN gradient would
+    poison the parameters for good): a step with non-finite local energies / loss / gradient is discarded -- walkers,
+    parameters and optimiser state keep their values, no CSV row is written for it (process.py:344), `rows` gets
+    ``{'step': t, 'rejected': True}``."""
     from . import checkpoint
-    gen = _rank_generator(key, data.device)
+    gen = _rank_generator(key, data.device, t_init)
     batch = data.shape[0]
     mcmc_step = qmc.make_mcmc_step(slog_net.apply, batch, latvec=simulation_cell.a, steps=mcmc_steps)
     total_energy = train.make_loss(logdet_net.apply, None, simulation_cell, clip_local_energy=clip_local_energy,
@@ -122,7 +130,7 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
     opt_init, opt_update = train.adam(learning_rate if learning_rate is not None else learning_rate_schedule())
     if opt_state is None:
         opt_state = opt_init(params)
-    step = train.make_training_step(mcmc_step, total_energy, opt_update)
+    step = train.make_training_step(mcmc_step, total_energy, opt_update, check_nan=check_nan)
     width = float(move_width)
     if t_init == 0:                                                      # process.py:256: burn-in only on a fresh start
         for _ in range(burn_in):
@@ -137,12 +145,15 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
     try:
         for t in range(t_init, t_init + iterations):
             data, params, opt_state, loss, aux, pmove, _ = step(t, data, params, opt_state, gen, width)
-            row = {'step': t, 'energy': float(loss) / scale, 'variance': float(aux.variance) / scale ** 2,
-                   'pmove': float(pmove), 'imaginary': float(aux.imaginary) / scale,
-                   'kinetic': complex(aux.kinetic.mean().item()) / scale, 'ewald': float(aux.ewald.mean()) / scale}
-            rows.append(row)
-            if writer:
-                writer.write(t, **row)
+            if loss is None:                                             # rejected step: nothing was updated, nothing is logged
+                rows.append({'step': t, 'rejected': True, 'pmove': float(pmove)})
+            else:
+                row = {'step': t, 'energy': float(loss) / scale, 'variance': float(aux.variance) / scale ** 2,
+                       'pmove': float(pmove), 'imaginary': float(aux.imaginary) / scale,
+                       'kinetic': complex(aux.kinetic.mean().item()) / scale, 'ewald': float(aux.ewald.mean()) / scale}
+                rows.append(row)
+                if writer:
+                    writer.write(t, **row)
             if t > 0 and t % adapt_frequency == 0:                       # process.py:368-373
                 if np.mean(pmoves) > 0.55:
                     width *= 1.1

@@ -168,15 +168,15 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
             (atoms is None and importance_sampling.system is system)
     if fused:
         _check_latvec(latvec, system)
-    gen_calls = {}                            # stateful torch.Generator keys: Philox offset advanced by `steps` per call
 
     def fused_step(params, data, key, width):
         """The default sampler (`ds_mcmc_step`), the one-electron sampler (`ds_mcmc_step_one_electron`), the importance-sampled
         one (`ds_mcmc_step_importance`) or the asymmetric proposal (`ds_mcmc_step_asymmetric`) as ONE C-ABI call:
         proposal, wrap, log|psi|, accept/select for all moves are enqueued back to back; the noise is Philox evaluated inside the kernels.  `key`: an int is a
         pure key like a JAX PRNGKey (same key -> same moves; the caller passes a fresh one per iteration, the rank is
-        folded in); a torch.Generator is stateful (its initial_seed keys the stream and every call advances the
-        offset by `steps`); a tuple (normals, uniforms) replays explicit noise."""
+        folded in); a torch.Generator is stateful -- the Philox key of a call is DRAWN from it, so the generator's own state
+        carries the stream position: closures sharing one generator never replay each other's noise, and a generator
+        restored to a saved state continues the same stream; a tuple (normals, uniforms) replays explicit noise."""
         data = data.clone()
         lp = torch.empty(data.shape[0], dtype=data.dtype, device=data.device)
         # one-electron moves (`ds_mcmc_step_one_electron`): N * steps moves, move i displaces electron i % N   qmc.py:355-358
@@ -188,9 +188,8 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
                                     importance=imp, atoms=atoms)
         else:
             if isinstance(key, torch.Generator):
-                seed = key.initial_seed()
-                _, off = gen_calls.get(id(key), (key, 0))
-                gen_calls[id(key)] = (key, off + nsteps)          # (holding the generator keeps its id unique)
+                r = torch.randint(0, 2 ** 31 - 1, (2,), generator=key, device=key.device).tolist()
+                seed, off = (r[0] << 31) | r[1], 0
             else:
                 seed, off = int(key) * max(1, constants.world_size()) + constants.rank(), 0
             nacc = system.mcmc_step(params, data, lp, nsteps, width, seed=seed, offset=off, first_electron=first, importance=imp,

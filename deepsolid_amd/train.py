@@ -120,23 +120,44 @@ def adam(learning_rate=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     return init, update
 
 
-def make_training_step(mcmc_step, val_and_grad, opt_update):
+def _tree_all_finite(tree):
+    if isinstance(tree, dict):
+        return all(_tree_all_finite(v) for v in tree.values())
+    if isinstance(tree, (list, tuple)):
+        return all(_tree_all_finite(v) for v in tree)
+    return bool(torch.isfinite(tree).all())
+
+
+def make_training_step(mcmc_step, val_and_grad, opt_update, check_nan=False):
     """train.py:147-184.  ``val_and_grad`` is ``total_energy.value_and_grad`` (tree gradient) or, to send one
     message per step, ``total_energy`` itself: its packed gradient is then averaged over the ranks with a
-    single all-reduce before it is unpacked."""
+    single all-reduce before it is unpacked.
+
+    ``check_nan`` (cfg.debug.check_nan, process.py:303-318): a step whose loss, local energies or search direction are
+    not finite is DISCARDED -- walkers, parameters and optimiser state keep their previous values and the step returns
+    ``loss = aux_data = None``, like the reference's ``except AssertionError`` branch.  The decision is taken BEFORE the
+    (in-place) optimiser update from quantities that are already identical on every rank (the all-reduced loss,
+    non-finite count and gradient), so all ranks skip together; it costs one device -> host read."""
     packed = getattr(val_and_grad, 'value_and_grad_packed', None)
 
     def step(t, data, params, state, key, mcmc_width):
-        data, pmove = mcmc_step(params, data, key, mcmc_width)
+        new_data, pmove = mcmc_step(params, data, key, mcmc_width)
         if packed is not None:
-            (loss, aux_data), flat = packed(params, data)
+            (loss, aux_data), flat = packed(params, new_data)
             flat = constants.pmean_if_pmap(flat)                       # :176-177, one RCCL all-reduce
-            search_direction = val_and_grad.system.unpack_grad(flat, params)
+            finite = not check_nan or bool(torch.isfinite(flat).all() & torch.isfinite(loss))
+            search_direction = val_and_grad.system.unpack_grad(flat, params) if finite else None
         else:
-            (loss, aux_data), search_direction = val_and_grad(params, data)
+            (loss, aux_data), search_direction = val_and_grad(params, new_data)
             search_direction = _tree_pmean(search_direction)
+            finite = not check_nan or (bool(torch.isfinite(loss)) and _tree_all_finite(search_direction))
+        if check_nan and finite and aux_data.n_nonfinite is not None:
+            finite = float(aux_data.n_nonfinite) == 0.0
+        if not finite:
+            # data, params, opt_state are not updated (process.py:314-318)
+            return data, params, state, None, None, pmove, None
         state, params = opt_update(t, search_direction, params, state)
-        return data, params, state, loss, aux_data, pmove, search_direction
+        return new_data, params, state, loss, aux_data, pmove, search_direction
     return step
 
 

@@ -265,6 +265,14 @@ int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_
 #define DS_PROF_KINDS 11
 int ds_profile_enable(ds_system* sys, int on);
 int ds_profile_read(ds_system* sys, double* ms_total, int64_t* launches);
+/* In-kernel clock probe of the dominant kernel (hidden one-electron layers), active while profiling is enabled for it: one
+ * wave per workgroup reads the shader-clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) at entry
+ * and exit; the sums over all workgroups since ds_profile_enable are returned.  shader_cycles / ref_ticks x 100 MHz is the
+ * clock the kernel actually ran at in that region (the MFMA peak scales with it). */
+int ds_profile_read_clock(ds_system* sys, double* shader_cycles, double* ref_ticks);
+/* Kernel-development aid: shader-clock stamps written by one wave of the hidden-layer kernel at its phase boundaries when the
+ * library runs with DS_LG_DBG=32 and profiling is enabled (tools/layer_timeline.py); n <= 1022 stamps. */
+int ds_debug_timeline(ds_system* sys, uint64_t* out, int n);
 
 /* Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters: copies n_elems float64
  * with the 8-byte-per-lane access pattern of the jet tensors (known traffic = 8 n read + 8 n written). */

@@ -243,6 +243,103 @@ def test_kinetic_energy_vs_reference_hamiltonian(name):
     np.testing.assert_allclose(ew, fx['ew_ref'], atol=1e-9 * max(1.0, np.abs(fx['ew_ref']).max()))
 
 
+@pytest.mark.parametrize('name', ['lih', 'lih_mixed', 'lih_narrow', 'li_polarized', 'bcc_li', 'bcc_li_fulldet', 'graphene'])
+def test_per_electron_layer_path_vs_reference_hamiltonian(name, monkeypatch):
+    """The one-electron layers have two device paths: the electron-group kernels of csrc/ds_layer.h (default; every other
+    test runs them) and the per-electron k_jet_gemm + k_shared_term + k_m2_expand path (DS_LAYER_GROUPS=0, read at system
+    creation).  The second must reproduce the reference-executed kinetic energies too, and both must agree to rounding."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    nw = len(fx['ke_ref'])
+    x = torch.as_tensor(fx['x'][:nw], device='cuda')
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('DS_LAYER_GROUPS', flag)
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
+        ke = sysd.local_energy(dp, x)[0]
+        out[flag] = torch.view_as_complex(ke).cpu().numpy()
+        for b in range(nw):
+            assert abs(out[flag][b] - fx['ke_ref'][b]) < 1e-9 * max(1.0, abs(fx['ke_ref'][b])), (flag, b, out[flag][b], fx['ke_ref'][b])
+    assert np.abs(out['1'] - out['0']).max() < 1e-10 * max(1.0, np.abs(out['0']).max())
+
+
+@pytest.mark.parametrize('name,dtype,B', [('bcc_li', torch.float64, 4096 + 3), ('diamond', torch.float32, 1024 + 5)])
+def test_full_batch_tiled_fixture_walkers(name, dtype, B):
+    """Parity at the sizes bench.py runs (BASELINE configs 3 and 5): the fixture's reference-executed walkers tiled to a
+    full batch with a ragged last chunk.  Every copy must equal ke_ref (1e-9 Ha relative in float64; the float32 budget
+    of test_float32_chain_vs_float64_oracle for diamond) and all copies of a walker must be BIT-identical wherever they
+    sit in the 1024-walker chunks -- no dependence on chunk position, workgroup placement or neighbours."""
+    from deepsolid_amd import hamiltonian, network
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=dtype, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    nw = len(fx['ke_ref'])
+    reps = (B + nw - 1) // nw
+    x = torch.as_tensor(np.tile(fx['x'][:nw], (reps, 1))[:B], dtype=dtype, device='cuda')
+    net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', dtype=dtype, **net_kw)
+    ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(dp, x)
+    ke = ke.cpu().numpy()
+    tol = 1e-9 if dtype == torch.float64 else 3e-4
+    for b in range(nw):
+        copies = ke[b::nw]
+        assert (copies == copies[0]).all(), (b, np.abs(copies - copies[0]).max())
+        assert abs(copies[0] - fx['ke_ref'][b]) < tol * max(1.0, abs(fx['ke_ref'][b])), (b, copies[0], fx['ke_ref'][b])
+    ewn = ew.cpu().numpy()
+    assert all((ewn[b::nw] == ewn[b]).all() for b in range(nw))
+
+
+@pytest.mark.parametrize('S,nelec', [(1, (1, 2)), ((2, 1, 1), (2, 4))])
+def test_more_down_than_up_electrons(S, nelec):
+    """n_dn > n_up (the reference accepts any cell.nelec): log|psi|, phase and E_kin against the oracle."""
+    from deepsolid_amd import hamiltonian, network, systems
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('bcc_li', S=S, nelec=nelec)
+    net_kw = dict(systems.DETNET_DEFAULTS)
+    params = make_test_params(77, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    xn = systems.synthetic_walkers(cell, 3, seed=8)
+    x = torch.as_tensor(xn, device='cuda')
+    ps = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_phase_and_slogdet', **net_kw)
+    phase, logabs = ps.apply(dp, x)
+    ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    ke, _ = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, x)
+    o_ps = oracle_net(cell, klist, net_kw, 'eval_phase_and_slogdet')
+    for b in range(3):
+        st = ofl.stages(p_cpu, tt(xn[b]), klist, cell, net_kw)
+        ph_ref, la_ref = o_ps.apply(p_cpu, tt(xn[b]))
+        assert abs(float(logabs[b]) - float(la_ref)) < 1e-10
+        assert abs(complex(phase[b].cpu()) - complex(ph_ref)) < 1e-10
+        assert abs(complex(ke[b].cpu()) - complex(st['ke'])) < 1e-9 * max(1.0, abs(complex(st['ke'])))
+
+
+def test_value_chain_log_det_propagates_nan():
+    """The register LU behind log|psi| in every Metropolis step (k_det_lu_val, n <= 16) must return NaN when the orbital
+    matrix holds a NaN -- like jnp.linalg.slogdet and like the Gauss-Jordan kernel of the local-energy chain -- so that a
+    move into such a configuration is REJECTED (lp2 - lp1 > log u is false) instead of being accepted with a finite value."""
+    from deepsolid_amd import network, qmc
+    fx, cell, klist, net_kw, params = load_case('bcc_li')
+    dp = dev_params(params)
+    x = torch.as_tensor(fx['x'][:4], device='cuda').clone()
+    x[1, 5] = float('nan')                                # one coordinate of walker 1
+    slog = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', **net_kw)
+    la = slog.apply(dp, x)
+    assert torch.isnan(la[1]) and torch.isfinite(la[[0, 2, 3]]).all()
+    ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    from deepsolid_amd import hamiltonian
+    ke, _ = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, x)
+    assert torch.isnan(ke[1].real) and torch.isfinite(torch.view_as_real(ke[[0, 2, 3]])).all()
+    # a Metropolis step that proposes NaN for one walker keeps that walker where it was
+    x0 = torch.as_tensor(fx['x'][:4], device='cuda')
+    nz = torch.zeros(1, 4, x0.shape[1], dtype=torch.float64, device='cuda')
+    nz[0, 2, 7] = float('nan')
+    un = torch.full((1, 4), 1e-300, dtype=torch.float64, device='cuda')          # log u = -690: every finite move is accepted
+    step = qmc.make_mcmc_step(slog.apply, 4, cell.a, steps=1)
+    x1, pm = step(dp, x0, (nz, un), 0.02)
+    assert torch.equal(x1[2], x0[2]) and abs(float(pm) - 0.75) < 1e-12
+
+
 @pytest.mark.parametrize('name', ['graphene', 'diamond'])
 def test_large_cells_local_energy_vs_autodiff_oracle(name):
     """48 / 96 electrons against the oracle's AUTODIFF `hessian`-mode restatement (hamiltonian.py:104-124), a
@@ -279,8 +376,9 @@ def test_large_cells_local_energy_vs_forward_laplacian_oracle(name):
 @pytest.mark.parametrize('name', ['lih', 'bcc_li', 'diamond'])
 def test_float32_chain_vs_float64_oracle(name):
     """fp32 instantiation (BASELINE config 5 is fp32; CDNA4 has no TF32, v_mfma_f32_16x16x4_f32 is
-    exact f32).  Tolerances are f32-roundoff class: log|psi| 2e-3 absolute (sums over up to 96
-    log-dets), local kinetic energy 2e-3 relative to max(1, |E_kin|)."""
+    exact f32).  Tolerances: log|psi| 2e-3 absolute (sums over up to 96 log-dets); local kinetic energy 10x the
+    measured float32 budget of test_float32_error_budget (7e-6 at 4 e-, 6e-6 at 24 e-, 2.7e-5 at 96 e-) relative to
+    max(1, |E_kin|): 1e-4 / 1e-4 / 3e-4."""
     from deepsolid_amd import hamiltonian, network
     fx, cell, klist, net_kw, params = load_case(name)
     dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v]
@@ -300,7 +398,8 @@ def test_float32_chain_vs_float64_oracle(name):
         # the f64 oracle evaluated at the f32-rounded walker the kernel actually saw
         xb = x[b].cpu().double()
         ref = complex(ofl.stages(p_cpu, xb, klist, cell, net_kw)['ke'])
-        assert abs(complex(ke[b].cpu()) - ref) < 2e-3 * max(1.0, abs(ref)), (complex(ke[b].cpu()), ref)
+        ke_tol = 3e-4 if name == 'diamond' else 1e-4
+        assert abs(complex(ke[b].cpu()) - ref) < ke_tol * max(1.0, abs(ref)), (complex(ke[b].cpu()), ref)
     assert np.abs(ew.cpu().numpy() - fx['ewald'][:nb].sum(-1)).max() < 2e-3 * max(1.0, np.abs(fx['ewald'][:nb].sum(-1)).max())
 
 

@@ -201,6 +201,61 @@ print('rank', r, 'ok')
     assert out.stdout.count('ok') == 2
 
 
+def test_training_step_rejects_non_finite_steps():
+    """process.py:303-318: with check_nan a step whose gradient / loss / local energies are not finite leaves the walkers,
+    the parameters and the optimiser state exactly as they were (Adam updates in place: the decision must come BEFORE
+    the update) and returns loss = aux = None; the next finite step proceeds normally.  Stub loss, the product's step."""
+    import torch
+    from deepsolid_amd import train
+
+    class StubSystem:
+        def unpack_grad(self, flat, params):
+            return {'w': flat[:6].reshape(2, 3), 'b': flat[6:8]}
+
+    class StubLoss:
+        system = StubSystem()
+        mode = 'ok'
+
+        def value_and_grad_packed(self, params, data):
+            flat = torch.arange(1, 9, dtype=torch.float64)
+            loss = torch.tensor(-1.0, dtype=torch.float64)
+            bad = torch.tensor(0.0, dtype=torch.float64)
+            if self.mode == 'nan_grad':
+                flat = flat.clone(); flat[3] = float('nan')
+            if self.mode == 'inf_loss':
+                loss = torch.tensor(float('inf'), dtype=torch.float64)
+            if self.mode == 'bad_walker':
+                bad = torch.tensor(2.0, dtype=torch.float64)
+            return (loss, train.AuxiliaryLossData(variance=torch.tensor(0.1), local_energy=None, imaginary=torch.tensor(0.0),
+                                                  kinetic=None, ewald=None, n_nonfinite=bad)), flat
+
+    loss_fn = StubLoss()
+    params = {'w': torch.ones(2, 3, dtype=torch.float64), 'b': torch.ones(2, dtype=torch.float64)}
+    init, update = train.adam(0.1)
+    state = init(params)
+    mcmc = lambda p, d, key, w: (d + 1.0, torch.tensor(0.5))
+    step = train.make_training_step(mcmc, loss_fn, update, check_nan=True)
+    x0 = torch.zeros(4, 12, dtype=torch.float64)
+    data, params, state, loss, aux, pmove, g = step(0, x0, params, state, 0, 0.1)
+    assert loss is not None and torch.equal(data, x0 + 1.0) and state['count'] == 1
+    snap = {k: v.clone() for k, v in params.items()}
+    m_snap = [m.clone() for m in state['m']]
+    for mode in ('nan_grad', 'inf_loss', 'bad_walker'):
+        loss_fn.mode = mode
+        d2, params, state, loss, aux, pmove, g = step(1, data, params, state, 0, 0.1)
+        assert loss is None and aux is None and g is None and float(pmove) == 0.5
+        assert d2 is data and state['count'] == 1                                   # walkers and optimiser untouched
+        assert all(torch.equal(params[k], snap[k]) for k in snap) and all(torch.equal(a, b) for a, b in zip(state['m'], m_snap))
+    loss_fn.mode = 'ok'
+    d3, params, state, loss, aux, pmove, g = step(2, data, params, state, 0, 0.1)
+    assert loss is not None and state['count'] == 2 and not torch.equal(params['w'], snap['w'])
+    # without check_nan (the reference's default) the step is applied whatever it contains
+    loss_fn.mode = 'nan_grad'
+    plain = train.make_training_step(mcmc, loss_fn, update)
+    _, params, state, loss, *_ = plain(3, data, params, state, 0, 0.1)
+    assert loss is not None and torch.isnan(params['w']).any()
+
+
 def test_checkpoint_reads_reference_layout_and_round_trips(tmp_path):
     """A file written the way reference checkpoint.py:94-124 writes it (np.savez of t / data / pickled
     params tree with a leading device axis / opt_state / mcmc_width) is read back; ours has the same layout."""
@@ -238,6 +293,12 @@ def test_checkpoint_reads_reference_layout_and_round_trips(tmp_path):
     _, p3, w3 = checkpoint.to_single_device(d2, p2, w2)
     np.testing.assert_array_equal(p3['double'][0]['b'], params['double'][0]['b'])
     assert abs(w3 - 0.05) < 1e-7
+    # the training driver passes the width as a python float: it must still get the device axis -- the reference restores it
+    # with jax.pmap(lambda x: x)(jnp.asarray(mcmc_width_ckpt)) (process.py:252, constants.py:29), which fails on a 0-d array
+    for wv in (0.07, np.float64(0.07), torch.tensor(0.07, dtype=torch.float64), np.asarray([0.07])):
+        out = checkpoint.save(str(tmp_path), 9, torch.as_tensor(x), tp, None, wv)
+        with np.load(out, allow_pickle=True) as ck:
+            assert ck['mcmc_width'].shape == (1,) and abs(float(ck['mcmc_width'][0]) - 0.07) < 1e-12
 
 
 def test_adam_state_survives_a_checkpoint_round_trip(tmp_path):
