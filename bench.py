@@ -41,40 +41,42 @@ def layer_flops(n_elec, kloc, nout):
     return 2.0 * n_elec * d * kloc * nout
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate passes, calibrated against a copy of
-    known size -- on gfx950 raw FETCH_SIZE is half the bytes, see profiles/*_pmc_traffic.json).
-    bench.py cannot run rocprofv3 around itself, so this is the value measured for the same kernel,
-    system and 1024-walker launch size when the profile was taken; None if no profile is committed."""
+def pmc_traffic(kernel_prefix, system, dtype_name, avg_launch_ms):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, calibrated against a copy of known size -- on gfx950 raw FETCH_SIZE is
+    half the bytes, see profiles/*_pmc_traffic.json).  bench.py cannot run rocprofv3 around itself, so this is the value
+    measured for the same kernel, system, dtype and 1024-walker launch size when the profile was taken.  It is only
+    reported when (a) the profile names this system and dtype and (b) the kernel's average duration in the profile run
+    agrees with this run's HIP-event average within 5 % -- otherwise the counters describe a different execution and
+    `traffic` stays null."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
         try:
             d = json.load(open(f))
+            if d.get('system', 'bcc_li') != system or d.get('dtype', 'f64') != dtype_name:
+                continue
             for name, e in d['kernels'].items():
                 if name.startswith(kernel_prefix) and 'read_bytes_per_launch' in e and 'write_bytes_per_launch' in e:
+                    ref_ms = e.get('avg_launch_ms', d.get('avg_launch_ms', {}).get(name))
+                    if ref_ms is None or abs(ref_ms - avg_launch_ms) > 0.05 * avg_launch_ms:
+                        continue
                     best = dict(bytes_per_launch=e['read_bytes_per_launch'] + e['write_bytes_per_launch'],
                                 read=e['read_bytes_per_launch'], write=e['write_bytes_per_launch'],
-                                walkers_per_launch=d.get('walkers_per_launch'), source=os.path.basename(f))
+                                walkers_per_launch=d.get('walkers_per_launch'), profile_avg_launch_ms=ref_ms,
+                                source=os.path.basename(f))
         except Exception:
             pass
     return best
 
 
-def pmc_clock(kernel_prefix):
-    """Shader clock while the dominant kernel runs, from the committed GRBM_GUI_ACTIVE pass (tools/pmc_clock.sh: cycles summed
-    over the 8 XCDs / kernel duration / 8); None if no profile is committed."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_clock.json'))):
-        try:
-            for name, e in json.load(open(f)).items():
-                if name.startswith(kernel_prefix) and e.get('clock_ghz'):
-                    best = dict(clock_ghz=e['clock_ghz'] / 8.0, source=os.path.basename(f))
-        except Exception:
-            pass
-    return best
+def gemm_instance(n_elec, dtype, epi):
+    """The k_jet_gemm<T, NB, ST, EPI> instantiation ds_api.hip::dispatch_tiles launches for this electron count
+    (NB x 16 features and ST x 16 jet slots per wave)."""
+    st = (3 * n_elec + 2 + 15) // 16
+    nb = 4 if st <= 5 else (2 if st <= 10 else (2 if dtype == torch.float32 else 1))
+    tname = 'double' if dtype == torch.float64 else 'float'
+    return f'k_jet_gemm<{tname},{nb},{st},{epi}>', nb, st
 
 
 def log(msg):
@@ -199,6 +201,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend ('nccl' is RCCL on ROCm; 'gloo' only for the launcher test on CPU hosts)")
+    ap.add_argument('--single-scaling', action='store_true', help='N > 1: measure only --scaling, not the other mode beside it')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / reduction plumbing only (no GPU work): every rank reports in, rank 0 prints the JSON line')
     args = ap.parse_args()
@@ -243,18 +246,41 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(xb, steps, warmup, with_profile):
+        """W warm-up steps, then exactly `steps` steps between barrier + synchronize; -> (seconds (max over ranks), loss, aux)."""
+        for _ in range(warmup):
+            loss, aux = total_energy(params, xb)
+        sync()
+        if with_profile:
+            sysd.profile(True, only='single_hidden')  # events + in-kernel clock probe on the hidden-layer kernel only
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, aux = total_energy(params, xb)
+        sync()
+        dt_ = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, loss, aux
+
     log(f'system {args.system}: N={sum(cell.nelec)} batch/GPU={args.batch} world={world}; warm-up')
-    for _ in range(args.warmup):
-        loss, aux = total_energy(params, x)
-    sync()
-    log('timed region')
-    sysd.profile(True, only='single_hidden')          # events around the dominant kernel only: the timed region stays undisturbed
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, aux = total_energy(params, x)
-    sync()
-    dt = time.perf_counter() - t0
+    dt, loss, aux = timed(x, args.steps, args.warmup, True)
+    log('timed region done')
     prof = sysd.profile_read()
+    clk_cycles, clk_ticks, clk_ghz = sysd.profile_clock()
+    # the other scaling mode in the same invocation (N > 1): BASELINE configs 4 / 5 split ONE global batch over the GPUs
+    # (process.py:72-77), the tier's convention is a fixed per-GPU batch -- both lines are measured, `value` is --scaling's
+    other = None
+    if world > 1 and not args.single_scaling:
+        # weak run: also ONE global batch of --batch walkers split over the ranks; strong run: also --batch walkers on every rank
+        ob = args.batch // world if args.scaling == 'weak' else global_batch
+        if ob >= 1 and (args.scaling == 'strong' or args.batch % world == 0):
+            xo = torch.as_tensor(systems.synthetic_walkers(cell, ob, seed=4321 + rank), dtype=dtype, device=dev)
+            sysd.profile(False)
+            dto, _, _ = timed(xo, args.steps, 1, False)
+            other = {'scaling': 'strong' if args.scaling == 'weak' else 'weak', 'batch_per_gpu': ob, 'global_batch': ob * world,
+                     'value': world * ob * args.steps / dto, 'ms_per_step': dto / args.steps * 1e3, 'steps': args.steps}
     sysd.profile(True)                                 # one extra, untimed step with events around every kernel: the breakdown
     total_energy(params, x)
     torch.cuda.synchronize()
@@ -288,9 +314,6 @@ def main():
         log(f"mcmc_step (20 moves, {args.batch} walkers): {ms:.1f} ms, log-psi forward {mcmc['logpsi_forward_ms']:.2f} ms, pmove {float(pm):.3f}")
     ranks_seen = 1
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         seen = torch.zeros(world, dtype=torch.float64, device=dev)
         seen[rank] = 1.0
         dist.all_reduce(seen)                               # every rank that ran the timed region reports in
@@ -303,12 +326,60 @@ def main():
     h1 = net_kw['hidden_dims'][0][0]
     h2 = net_kw['hidden_dims'][0][1]
     nch = 2 if cell.nelec[1] else 1
-    f_layer = layer_flops(n_e, h1 + nch * h2, h1)
-    ms_hidden, n_launch = prof['single_hidden']
+    ndet = int(net_kw['determinants'])
+    peak = PEAK_TFLOPS[dtype]
     n_hidden = len(net_kw['hidden_dims']) - 1
+    # algorithmic FLOPs per walker of the two MFMA kernels that can dominate a step
+    f_layer = layer_flops(n_e, h1 + nch * h2, h1)                         # one hidden layer, all electrons
+    f_orb = sum(2.0 * ns * (3 * n_e + 2) * h1 * (2 * ns * ndet) for ns in cell.nelec if ns)     # orbital head, both spins
+    kms = {k: v[0] for k, v in prof_all.items()}                          # ms per kernel kind in the extra profiled step
+    hidden_name, nb, st = gemm_instance(n_e, dtype, 2)
+    oc = (2 * cell.nelec[0] * ndet + 63) // 64 * 64                       # packed orbital columns of the spin-up head (ds_api.hip)
+    orb_name = gemm_instance(n_e, dtype, 5)[0]
+    if nb == 4 and st <= 5 and oc % 256 != 0 and oc % 192 == 0:           # the 48-column-per-wave instance
+        orb_name = orb_name.replace(f',{nb},{st},5>', f',3,{st},5>')
+    if os.environ.get('DS_LAYER_GROUPS', '0') not in ('', '0'):
+        hidden_name = 'k_layer_unit<%s,true,2,false> + k_layer_fin' % ('double' if dtype == torch.float64 else 'float')
+    # the roofline object describes the kernel with the largest share of the step
+    ms_hidden, n_launch = prof['single_hidden']
     flops_total = f_layer * args.batch * n_hidden * args.steps           # this rank, timed region
     achieved = flops_total / (ms_hidden * 1e-3) / 1e12 if ms_hidden > 0 else 0.0
-    peak = PEAK_TFLOPS[dtype]
+    hidden_obj = {'bound': 'mfma', 'kernel': hidden_name + ' (hidden one-electron layers: K=%d MFMA GEMM + fused tanh-jet epilogue)' % (h1 + nch * h2),
+                  'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None, 'traffic_detail': None,
+                  'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch, 'flops_per_walker_layer': f_layer,
+                  'timing': 'HIP events inside the library around every launch of this kernel over the timed region',
+                  'share_of_step': kms.get('single_hidden', 0.0) / max(sum(kms.values()), 1e-9)}
+    if clk_ghz:
+        # measured IN THIS RUN: one wave per workgroup of this kernel reads s_memtime (shader clock) and s_memrealtime (100 MHz)
+        # at entry and exit; sum of cycles / sum of ticks over every workgroup of the timed region
+        hidden_obj['shader_clock_ghz'] = clk_ghz
+        hidden_obj['clock_source'] = 'in-kernel s_memtime / s_memrealtime, all workgroups of the timed region'
+        hidden_obj['peak_at_measured_clock'] = peak * clk_ghz / 2.4
+        hidden_obj['frac_at_measured_clock'] = achieved / (peak * clk_ghz / 2.4)
+    orb_ms = kms.get('orbital', 0.0)
+    orb_ach = f_orb * args.batch / (orb_ms * 1e-3) / 1e12 if orb_ms > 0 else 0.0
+    orbital_obj = {'bound': 'mfma', 'kernel': orb_name + ' (orbital head: K=%d MFMA GEMM + fused envelope x phase product rule)' % h1,
+                   'achieved': orb_ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': orb_ach / peak, 'traffic': None,
+                   'flops_per_walker': f_orb, 'timing': 'HIP events, one extra profiled step outside the timed region',
+                   'share_of_step': orb_ms / max(sum(kms.values()), 1e-9)}
+    dominant = 'single_hidden' if kms.get('single_hidden', 0.0) >= orb_ms else 'orbital'
+    roofline = hidden_obj if dominant == 'single_hidden' else orbital_obj
+    if mcmc:
+        # Metropolis path: executed FLOPs of one log|psi| forward (value chain: the same contractions with one column per
+        # walker: layers incl. the shared term, pair stream, orbital head) / its duration / peak
+        hd = net_kw['hidden_dims']
+        k1 = [4 * len(np.asarray(cell.original_cell.atom_coords()).reshape(-1, 3))] + [h[0] for h in hd]
+        k2 = [4] + [h[1] for h in hd]
+        f_fwd = 0.0
+        for l in range(len(hd)):
+            f_fwd += 2.0 * n_e * (k1[l] + nch * k2[l]) * k1[l + 1] + 2.0 * nch * k1[l] * k1[l + 1]      # per-electron rows + shared term
+            if l < len(hd) - 1:
+                f_fwd += 2.0 * n_e * n_e * k2[l] * k2[l + 1]                                            # pair stream
+        f_fwd += sum(2.0 * ns * k1[-1] * 2 * ns * ndet for ns in cell.nelec if ns)                       # orbital head
+        mcmc['forward_flops_per_walker'] = f_fwd
+        mcmc['roofline'] = {'bound': 'mfma', 'achieved': f_fwd * args.batch / (mcmc['logpsi_forward_ms'] * 1e-3) / 1e12, 'peak': peak,
+                            'unit': 'TFLOP/s'}
+        mcmc['roofline']['frac'] = mcmc['roofline']['achieved'] / peak
     out = {
         'metric': 'local-energy evals/sec', 'value': world * args.batch * args.steps / dt,
         'unit': 'local-energy evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -319,32 +390,20 @@ def main():
                    'batch_per_gpu': args.batch, 'global_batch': global_batch, 'parallelism': f'walker-dp{world}'},
         'ranks_seen': ranks_seen,
         'energy_mean_ha': float(loss), 'energy_imag_ha': float(aux.imaginary), 'variance': float(aux.variance),
-        'roofline': {'bound': 'mfma', 'kernel': 'k_jet_gemm<%s,4,5,2> (hidden one-electron layers: K=%d MFMA GEMM + fused tanh-jet epilogue)' % ('double' if dtype == torch.float64 else 'float', h1 + nch * h2),
-                     'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                     'traffic': None, 'traffic_detail': None, 'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch,
-                     'flops_per_walker_layer': f_layer,
-                     # measured issue rate of the MFMA the kernel uses (tools/gpu_probe.py, profiles/r01_mfma_f64_probe.json): the
-                     # datasheet rate is reachable with VGPR accumulators (51.5 TFLOP/s with AGPR accumulators); `frac` uses `peak`
-                     'instruction_rate': {'v_mfma_f64_16x16x4_f64': 77.7, 'unit': 'TFLOP/s'} if dtype == torch.float64 else None},
-        'kernel_ms_per_step': {k: v[0] for k, v in prof_all.items()},     # from one extra untimed step
+        'roofline': roofline,
+        'roofline_other_kernels': {'orbital_head': orbital_obj} if dominant == 'single_hidden' else {'hidden_layers': hidden_obj},
+        'kernel_ms_per_step': kms,     # from one extra untimed step
         'mcmc': mcmc,
     }
-    clk = pmc_clock('ds::k_jet_gemm<double, 4, 5, 2>') if (args.system == 'bcc_li' and dtype == torch.float64) else None
-    if clk:
-        # the chip does not hold its 2.4 GHz boost clock under this kernel (power): the MFMA peak AT THE MEASURED CLOCK is
-        # peak * clock / 2.4; `frac` above stays relative to the datasheet peak
-        out['roofline']['shader_clock_ghz'] = clk['clock_ghz']
-        out['roofline']['clock_source'] = clk['source']
-        out['roofline']['peak_at_measured_clock'] = peak * clk['clock_ghz'] / 2.4
-        out['roofline']['frac_at_measured_clock'] = achieved / (peak * clk['clock_ghz'] / 2.4)
-    if args.system == 'bcc_li' and dtype == torch.float64:
-        tr = pmc_traffic('ds::k_jet_gemm<double, 4, 5, 2>')
-        if tr:
-            out['roofline']['traffic'] = tr['bytes_per_launch']
-            p_slots = (3 * n_e + 2 + 15) // 16 * 16
-            # read every layer-input row once, write every output row once (weights and S are L2-resident)
-            tr['algorithmic_bytes_per_launch'] = 8.0 * tr['walkers_per_launch'] * n_e * p_slots * ((h1 + nch * h2) + h1)
-            out['roofline']['traffic_detail'] = tr
+    if other:
+        out['other_scaling'] = other
+    tr = pmc_traffic('ds::' + hidden_name.split(' ')[0].replace(',', ', '), args.system, args.dtype, hidden_obj['avg_launch_ms'])
+    if tr:
+        hidden_obj['traffic'] = tr['bytes_per_launch']
+        p_slots = (3 * n_e + 2 + 15) // 16 * 16
+        # read every layer-input row once, write every output row once (weights and S are L2-resident)
+        tr['algorithmic_bytes_per_launch'] = (8.0 if dtype == torch.float64 else 4.0) * tr['walkers_per_launch'] * n_e * p_slots * ((h1 + nch * h2) + h1)
+        hidden_obj['traffic_detail'] = tr
     if world == 1 and not args.no_cpu_baseline:
         params_np = {k: [{kk: vv.cpu().numpy() for kk, vv in d.items()} for d in v] for k, v in params.items()}
         cb, err = cpu_baseline(cell, klist, net_kw, params_np, x_np, aux.local_energy[:8].cpu().numpy(), args.cpu_seconds)

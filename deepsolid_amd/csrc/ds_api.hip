@@ -49,7 +49,8 @@ void inv3(const double* a, double* o) {
 // per-walker workspace carve, in elements
 struct WsLayout {
     size_t G, MEAN, ZB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
-    size_t M2V = 0;                                        // partner means of the pair stream as 5-jets (ds_layer.h)
+    size_t M2V = 0;                                        // partner sums of the pair stream as 5-jets (ds_layer.h)
+    size_t LAY = 0;                                        // per-electron arrays of the layer kernels: y, y' z_L, slot-tile sums of squares
     size_t PARTM = 0;                                      // value chain: per-tile segment sums of the pair layer (k_two_layer)
     size_t mout_off[2], minv_off[2], dets_off[2], tr_off[2];
     size_t per_walker;                                     // total elements per walker
@@ -77,11 +78,11 @@ struct ds_system {
     bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
-    int lg_tile = 42;                 // DS_LG_TILE: 10 * (electrons per pass) + waves per SIMD of k_layer_group
+    bool lg_gather = false;           // DS_LG_GATHER=1: hidden layers gather the pair-mean rows too (layer 0 always does)
     int lg_ring = 2;                  // DS_LG_RING: operand ring depth of k_layer_group (2 or 4)
     int lg_dbg = 0;                   // DS_LG_DBG (timing experiments, wrong results)
     size_t lg_pad_lds = 0;            // DS_LG_PAD_LDS (experiment): extra dynamic LDS per workgroup of k_layer_group
-    bool layer_groups = true;         // electron-group layer kernels (ds_layer.h); DS_LAYER_GROUPS=0 selects the per-electron k_jet_gemm path
+    bool layer_groups = false;        // DS_LAYER_GROUPS=1: electron-group layer kernels (ds_layer.h) instead of the per-electron k_jet_gemm path
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
@@ -283,6 +284,7 @@ void build_layouts(ds_system* s) {
     w.G = (size_t)S.N * S.ldk * S.P;
     w.MEAN = (size_t)S.n_groups * h1max * S.P;       // (>= nch: also holds the per-group partial spin means of a layer's output)
     w.M2V = (size_t)rup(S.N * S.nch * h2max * 5, 16);
+    w.LAY = (size_t)S.N * h1max * (2 + S.P / 16);
     w.ZB = (size_t)std::max(h1max, std::max(S.ocols[0], S.ocols[1])) * S.P;   // shared spin-mean term S of one layer / orbital head
     for (int c = 0; c < S.nch; ++c)                  // ... or the orbital GEMM output of one spin
         w.ZB = std::max(w.ZB, (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * S.P);
@@ -298,7 +300,7 @@ void build_layouts(ds_system* s) {
         tr += (size_t)S.K * 2 * S.P;
     }
     w.MOUT = mo; w.MINV = rup((int)mi, 16); w.DETS = rup((int)de, 16); w.TR = tr;
-    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR + w.M2V;
+    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR + w.M2V + w.LAY;
     // value chain: the slot axis carries PV walkers (ds_value.h)
     WsLayout& v = s->wsv;
     const size_t PV = ds::PV;
@@ -315,14 +317,14 @@ void build_layouts(ds_system* s) {
         v.mout_off[c] = mo;
         mo += (size_t)S.K * n * n * 2 * PV;
     }
-    v.MOUT = mo; v.MINV = 0; v.TR = 0; v.M2V = 0;
+    v.MOUT = mo; v.MINV = 0; v.TR = 0; v.M2V = 0; v.LAY = 0;
     v.DETS = w.DETS * PV;             // DETS stays per walker
     v.PARTM = (size_t)(PV / 5) * h2max * 5 * (S.NP / 16) * ds::PM_SLOTS;
     v.per_walker = 2 * v.G + 2 * v.MEAN + v.ZB + 2 * v.H2 + v.Q + v.MOUT + v.DETS + v.PARTM;
 }
 
 template <typename T> struct Carve {
-    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR, *M2V;
+    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR, *M2V, *LAY;
 };
 template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     const WsLayout& w = s->ws;
@@ -338,6 +340,7 @@ template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     c.DETS = p; p += w.DETS * Bc;
     c.TR = p; p += w.TR * Bc;
     c.M2V = p; p += w.M2V * Bc;
+    c.LAY = p; p += w.LAY * Bc;
     return c;
 }
 
@@ -421,12 +424,15 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         // electron-group layer kernel (ds_layer.h): pair-mean rows generated in the operand load, spin means of the output
         // formed in the epilogue.  The per-electron path below stays for DS_LAYER_GROUPS=0 and for the stage dumps.
         const bool grouped = s->layer_groups && K2 % 4 == 0 && Kh % 4 == 0;
-        if (grouped) {
+        // the pair-mean rows of the layer input: gathered from the pair stream in the operand load (layer 0 and DS_LG_GATHER=1:
+        // only the partner sums are needed), or expanded to dense jet rows of G first
+        const bool gather = grouped && (s->lg_gather || Kh % 8 != 0 || K2 % 8 != 0);
+        if (gather) {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
             hipLaunchKernelGGL((ds::k_m2_means<T>), dim3(S.N, (unsigned)Bc), dim3(256), 0, st, S, c.H2[hi], K2, c.M2V, L.M2V);
         }
         // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
-        if (!grouped || stop == STOP_G0 + l) {
+        if (!gather || stop == STOP_G0 + l) {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
             hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
                                c.H2[hi], K2, c.G[gi], Kh);
@@ -488,30 +494,38 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
                 dim3 gblock; unsigned ggz;
                 gemm_geom(Nout, 4, &gblock, &ggz);
+                const size_t lay = (size_t)S.N * Nout;
                 ds::LayerArgs<T> la{c.G[gi], c.G[gi ^ 1], gws, gts, blk(s->i_wloc[l]), Kh, K2, Nout, c.ZB, c.H2[hin], (size_t)K2 * 5 * S.NP,
-                                    c.M2V, L.M2V, c.MEAN[1], L.MEAN, S.zero,
-                                    (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) ? s->clk_dev : nullptr, s->lg_dbg};
-                const size_t lds = ds::layer_group_lds_bytes<T>(gblock.x) + s->lg_pad_lds;
-                const dim3 ggrid(S.n_groups * ggz, (unsigned)Bc, 1);
-                const int pipe = (s->lg_ring == 4 && Kh % 16 == 0 && K2 % 16 == 0) ? 4 : ((Kh % 8 == 0 && K2 % 8 == 0) ? 2 : 0);
-#define DS_LG(RESV, PIPEV, STV, WPSV) hipLaunchKernelGGL((ds::k_layer_group<T, RESV, PIPEV, STV, WPSV>), ggrid, gblock, lds, st, S, la)
-                // (DS_LG_TILE = 10 * ST + WPS selects the experimental tile shapes of the residual hidden layers)
-                if (res && pipe == 4 && s->lg_tile == 22) DS_LG(true, 4, 2, 2);
-                else if (res && pipe >= 2 && s->lg_tile == 23) DS_LG(true, 2, 2, 3);
-                else if (res && pipe >= 2 && s->lg_tile == 32) DS_LG(true, 2, 3, 2);
-                else if (res && pipe == 4) DS_LG(true, 4, 4, 2);
-                else if (res && pipe == 2) DS_LG(true, 2, 4, 2);
-                else if (res) DS_LG(true, 0, 4, 2);
-                else if (pipe >= 2) DS_LG(false, 2, 4, 2);
-                else DS_LG(false, 0, 4, 2);
-#undef DS_LG
+                                    c.M2V, L.M2V, c.MEAN[1], L.MEAN, c.LAY, c.LAY + lay * Bc, c.LAY + 2 * lay * Bc, lay, 0, 1, S.zero,
+                                    (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) ? s->clk_dev : nullptr,
+                                    s->lg_dbg};
+                const size_t lds = ds::layer_unit_lds_bytes<T>(gblock.x) + s->lg_pad_lds;
+                const int ntile = S.P / 16;
+                const int Ktot = Kh + S.nch * K2;
+                const int pipe = gather ? 0 : ((s->lg_ring == 4 && Ktot % 16 == 0) ? 4 : (Ktot % 8 == 0 ? 2 : 0));
+                // slot tile 0 first (it produces y = tanh(z_0) of every electron), then all the other tiles, then the Laplacian slot
+                for (int part = 0; part < 2; ++part) {
+                    la.t0 = part; la.nt = part == 0 ? 1 : ntile - 1;
+                    if (la.nt < 1) continue;
+                    const dim3 ggrid(la.nt * S.n_groups * ggz, (unsigned)Bc, 1);
+#define DS_LU(RESV, PIPEV, GV) hipLaunchKernelGGL((ds::k_layer_unit<T, RESV, PIPEV, GV>), ggrid, gblock, lds, st, S, la)
+                    if (gather) { if (res) DS_LU(true, 0, true); else DS_LU(false, 0, true); }
+                    else if (res) { if (pipe == 4) DS_LU(true, 4, false); else if (pipe == 2) DS_LU(true, 2, false); else DS_LU(true, 0, false); }
+                    else { if (pipe >= 2) DS_LU(false, 2, false); else DS_LU(false, 0, false); }
+#undef DS_LU
+                }
+                if (res) hipLaunchKernelGGL((ds::k_layer_fin<T, true>), dim3(S.n_groups, (unsigned)Bc), dim3(Nout), 0, st, S, la);
+                else hipLaunchKernelGGL((ds::k_layer_fin<T, false>), dim3(S.n_groups, (unsigned)Bc), dim3(Nout), 0, st, S, la);
             } else {
                 // ... then the N electron tiles with the fused epilogue
                 ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
-                if (res)
+                if (res) {
+                    ds::OrbEpi<T> oe_clk{};
+                    if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) oe_clk.clk = s->clk_dev;
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
-                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), oe_clk);
+                }
                 else
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
@@ -550,7 +564,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             ProfScope ps(s, DS_PROF_ORBITAL, st);
             const int ch = S.mat_ch[sp];
             ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
-                             S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr};
+                             S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
             // 192 columns (n_s*K = 96) would give 3 waves of 64 columns per workgroup and leave SIMDs with a single wave;
             // 48-column waves give 4 balanced waves (the MFMA pipe needs >= 2 waves per SIMD, profiles/r01_mfma_f64_probe.json)
             if (NB == 4 && ST <= 5 && OC % 256 != 0 && OC % 192 == 0) {
@@ -1333,7 +1347,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     if (const char* e = getenv("DS_LG_PAD_LDS")) s->lg_pad_lds = (size_t)atol(e);
     if (const char* e = getenv("DS_LG_DBG")) s->lg_dbg = atoi(e);
     if (const char* e = getenv("DS_LG_RING")) s->lg_ring = atoi(e);
-    if (const char* e = getenv("DS_LG_TILE")) s->lg_tile = atoi(e);
+    if (const char* e = getenv("DS_LG_GATHER")) s->lg_gather = atoi(e) != 0;
     if (s->n_streams == 2) {
         bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
         // DS_CUMASK=1: each side stream owns one half of the CU mask bits (experiment: chunks at different phases on disjoint CUs)

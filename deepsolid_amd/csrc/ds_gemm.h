@@ -28,6 +28,9 @@ template <typename T> struct OrbEpi {
     int N, i0, nparam, nparam_max;
     int norb, n, row0;              // orbitals per det, matrix size, first matrix row of this spin's electrons
     const T* bias;                  // optional orbital bias (2*nparam: Re then Im), value slot only; or null
+    // optional in-kernel clock probe (hidden layers, EPI = 2, while profiling): wave 0 of every workgroup adds its shader-clock
+    // cycles (s_memtime) to clk[0] and its constant-rate 100 MHz ticks (s_memrealtime) to clk[1]
+    unsigned long long* clk;
 };
 
 // Residual stash (EPI = 2 / 4): the residual rows of a layer are rows n0..n0+16*NB-1 of the SAME tile the wave streams as
@@ -98,6 +101,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     }
     const int lr = lane & 15, lq = lane >> 4, n0 = (zb * (blockDim.x >> 6) + wave) * 16 * NB;
     if (n0 >= Nout) return;                      // column blocks beyond Nout (grid.z rounds up)
+    long long clk_c0 = 0, clk_r0 = 0;
+    if (EPI == 2 && oe.clk && wave == 0) { clk_c0 = clock64(); clk_r0 = wall_clock64(); }
     const T* Xp;
     const T* Wp;
     int nks;
@@ -349,6 +354,10 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 __builtin_nontemporal_store(o, &Go[n * P + 16 * s]);      // streamed out: the next reader comes after the whole launch
             }
         }
+    }
+    if (EPI == 2 && oe.clk && wave == 0 && lane == 0) {
+        atomicAdd(oe.clk, (unsigned long long)(clock64() - clk_c0));
+        atomicAdd(oe.clk + 1, (unsigned long long)(wall_clock64() - clk_r0));
     }
 }
 

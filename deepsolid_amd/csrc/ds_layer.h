@@ -1,32 +1,31 @@
 // ds_layer.h -- one-electron-stream layer of the forward-Laplacian chain, "electron group" formulation (round 3).
 //
-//   k_layer_group   z_i = W_loc^T [h_i ; mean_j h2_ji] + S  ->  tanh chain rule on the jets  ->  residual  ->  G_out
-//                   for a GROUP of up to LG_GE electrons of one spin per workgroup (network.py:305-332, 521-528).
-//   k_m2_means      the partner means of the pair stream as 5-jets (value, d/dr, Laplacian) per (electron, spin, feature).
+//   k_layer_unit    z_i = W_loc^T [h_i ; mean_j h2_ji] + S  ->  tanh chain rule on the jets  ->  residual  ->  G_out
+//                   for ONE 16-slot tile of a GROUP of up to LG_GE electrons of one spin per workgroup (network.py:305-332, 521-528).
+//   k_layer_fin     the Laplacian slot of the layer output (needs the sum of squares over ALL slot tiles of an electron).
+//   k_m2_means      the partner sums of the pair stream as 5-jets (value, d/dr, Laplacian) per (electron, spin, feature).
 //   k_group_fold    partial spin means of several groups -> one mean per spin.
 //
 // Why groups.  A workgroup of k_jet_gemm owns ONE electron, so the spin means of a layer's output (the next layer's shared
 // term) needed a second pass over all of G (k_shared_term: 4 GB per 1024-walker launch at 24 electrons), and the pair-mean
 // rows of the layer input had to be expanded to dense jet rows in HBM first (k_m2_expand: 1.4 GB per launch).  Here the
-// four waves of a workgroup (64 output features each) walk the group's electrons four at a time: a "pass" is one 16-slot
-// tile of four electrons (4 x 4 accumulator tiles).  With the slot tile as the OUTER loop
-//   * the sum over the group's electrons of an output tile is a lane-local sum over accumulator tiles, carried in 16
-//     registers across the passes of a slot tile and written once: MEANP[walker][group][n][slot] (already divided by the
-//     spin's electron count) -- the input of the next layer's shared term, no second pass over G;
-//   * the rows k >= Kh of the B operand (pair means) are generated in the operand load from the pair stream's 5-jets:
+// four waves of a workgroup (64 output features each) walk the group's electrons four at a time for one slot tile: a "pass"
+// is one 16-slot tile of four electrons (4 x 4 accumulator tiles), and
+//   * the sum over the group's electrons of the output tile is a lane-local sum over accumulator tiles, carried across the
+//     passes and written once: MEANP[walker][group][n][slot] (already divided by the spin's electron count) -- the input of
+//     the next layer's shared term, no second pass over G;
+//   * the rows k >= Kh of the jet operand (pair means) are generated in the operand load from the pair stream's 5-jets:
 //     slot (j, c) of row (spin s, k2) of electron i is  H2[k2][1+c][i*N+j] / n_s  (j in s, j != i),  -mean_c (j == i),
 //     the mean value / Laplacian for slots 0 / 1, zero otherwise (network.py:323-328; d/dx_j = +d/dr, d/dx_i = -d/dr);
-//   * the per-electron quantities that tie the slot tiles of an electron together -- y = tanh(z_0) and the Laplacian
-//     accumulator  y' z_L + y'' sum_d z_d^2 -- live in wave-private LDS (one value per lane: lane <-> feature), so no
-//     barrier is needed anywhere; the Laplacian slot is written by a short final step.
+//   * what ties the slot tiles of an electron together goes through three small per-electron arrays instead of a second
+//     pass: y = tanh(z_0) (written by the launch of slot tile 0, read by the launch of the other tiles), the partial sums
+//     of squares per tile, and y' z_L; k_layer_fin assembles the Laplacian slot  y' z_L + y'' sum_d z_d^2  from them.
 #pragma once
 #include "ds_gemm.h"
 
 namespace ds {
 
-constexpr int LG_GE = 12;   // electrons per group (three passes per slot tile)
-constexpr int LG_LDS_PER_WAVE = 2 * LG_GE * 64;                // elements of wave-private LDS (y and the Laplacian accumulator per electron and feature)
-template <typename T> inline size_t layer_group_lds_bytes(unsigned threads) { return (size_t)(threads / 64) * LG_LDS_PER_WAVE * sizeof(T); }
+constexpr int LG_GE = 12;   // electrons per group (three passes of four per slot tile)
 
 template <typename T> struct LayerArgs {
     const T* Gin;          // [walker][electron][ldk rows][P]   rows 0..Kh-1: h_i
@@ -41,12 +40,17 @@ template <typename T> struct LayerArgs {
     size_t m2v_ws;
     T* MEANP;              // [walker][group][Nout][P] partial spin means of the output
     size_t mp_ws;
-    // optional in-kernel clock probe (ds_profile_*): wave 0 of every workgroup adds its shader-clock cycles (s_memtime) and
-    // its constant-rate 100 MHz ticks (s_memrealtime) between entry and exit: clk[0] += cycles, clk[1] += ticks
+    // per-electron quantities that tie the slot tiles of an electron together (lay_ws = walker stride of each, elements):
+    T* Y;                  // [walker][electron][Nout]         y = tanh(z_0): written by the slot-tile-0 launch, read by the others
+    T* ZLD;                // [walker][electron][Nout]         y' z_L (the linear part of the Laplacian slot), from slot tile 0
+    T* SSP;                // [walker][slot tile][electron][Nout]  sum over the tile's gradient slots of z_d^2
+    size_t lay_ws;
+    int t0, nt;            // slot tiles [t0, t0 + nt) are handled by this launch
     const T* zero;         // one element holding 0 (the B operand of lanes that contribute nothing in a pair sub-phase)
-    unsigned long long* clk;
-    int dbg;               // timing experiments only (DS_LG_DBG): 1 = skip the epilogue arithmetic, 2 = skip the pair-mean rows, 4 = skip the G rows
+    unsigned long long* clk;   // optional in-kernel clock probe (ds_profile_*): clk[0] += shader cycles, clk[1] += 100 MHz ticks per workgroup
+    int dbg;               // timing experiments only (DS_LG_DBG)
 };
+template <typename T> inline size_t layer_unit_lds_bytes(unsigned threads) { return (size_t)(threads / 64) * 2 * 16 * 64 * sizeof(T); }
 
 // M2V[w][e][sp][k2][comp] = sgn(comp) sum_{j in sp} H2[w][k2][comp][e*N + j]  with sgn = -1 for the gradient components 1..3
 // (d/dx_e of h2[j][e](x_j - x_e) = -d/dr) and +1 for value / Laplacian (comp 4 already holds the full Laplacian).  SUMS, not
@@ -160,11 +164,14 @@ template <typename T, typename B> __device__ __forceinline__ void store_own(B* b
 
 // PIPE = 4 / 2: operand ring of that many k-steps with straight-line phase transitions (needs Kh and K2 multiples of 4 PIPE:
 // the hidden layers); PIPE = 0: a plain load / multiply loop (layer 0: K = 4A + nch * 4).
-// ST = electrons (column tiles) per pass, WPS = waves per SIMD the register budget is cut for.
-template <typename T, bool RES, int PIPE, int ST, int WPS>
-__global__ void __launch_bounds__(256, WPS) k_layer_group(SysDev<T> S, LayerArgs<T> A) {
+// grid (nt * n_groups * column blocks, walkers): workgroup = (slot tile t0 + ., electron group, 256 features), four waves.
+// GATHER: the rows k >= Kh come from the pair stream (above); otherwise all Kh + nch K2 rows are read from G (k_m2_expand ran).
+// ST = electrons (column tiles) per pass: 4, or 3 (leaves registers for a four-deep ring and the spin sums).
+template <typename T, bool RES, int PIPE, bool GATHER, int ST = 4>
+__global__ void __launch_bounds__(256, 2) k_layer_unit(SysDev<T> S, LayerArgs<T> A) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int NB = 4;
+    constexpr bool MSUM_REG = ST < 4;                      // spin sums in registers when the accumulators leave room
     // XCD-aware placement as in k_jet_gemm: all workgroups of one walker get linear ids of one residue class mod 8
     int gx = blockIdx.x, w = blockIdx.y;
     if ((gridDim.y & 7) == 0) {
@@ -172,199 +179,177 @@ __global__ void __launch_bounds__(256, WPS) k_layer_group(SysDev<T> S, LayerArgs
         w = (q / gridDim.x) * 8 + (b & 7);
         gx = q % gridDim.x;
     }
-    const int gzf = gridDim.x / S.n_groups, zb = gx % gzf, g = gx / gzf;
+    const int gzf = gridDim.x / (S.n_groups * A.nt), zb = gx % gzf, g = (gx / gzf) % S.n_groups, t = A.t0 + gx / (gzf * S.n_groups);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4, n0 = (zb * (blockDim.x >> 6) + wave) * 16 * NB;
     const int Nout = A.Nout;
     if (n0 >= Nout) return;                               // (no barriers below: the LDS state is wave-private)
     long long clk_c0 = 0, clk_r0 = 0;
     if (A.clk && wave == 0) { clk_c0 = clock64(); clk_r0 = wall_clock64(); }
-    // Phase skew.  The two waves that share a SIMD run identical work and would stay in lockstep -- both in the MFMA loop (sharing
-    // the matrix pipe), then both in the latency-bound epilogue with the pipe idle.  The wave in the odd hardware slot starts
-    // half a main loop late, so that one wave's epilogue runs under the other's MFMAs.  Timing only: no result depends on it.
     // (timing experiment, DS_LG_DBG & 32: wave 0 of workgroup 0 writes shader-clock stamps at its phase boundaries to clk[2 + i])
     unsigned long long* tl = (A.clk && (A.dbg & 32) && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0) ? A.clk + 2 : nullptr;
     int n_tl = 0;
     auto stamp = [&]() {
         if (tl && n_tl < 1000) { __builtin_amdgcn_s_waitcnt(0); tl[n_tl++] = (unsigned long long)clock64(); }
     };
-    if (A.dbg & 8) {
-        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));        // HW_ID.wave_id: wave slot of the SIMD
-        if (A.dbg & 16) {            // experiment: pseudo-random skew per workgroup
-            const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, h = (b * 2654435761u) >> 28;
-            for (unsigned i = 0; i < h * (unsigned)(A.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
-        } else if (slot & 1u) {
-            for (int i = 0; i < (A.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     extern __shared__ __attribute__((aligned(16))) char lg_smem[];
-    T* ylds = reinterpret_cast<T*>(lg_smem) + (size_t)wave * LG_LDS_PER_WAVE;       // [electron of the group][feature]: y = tanh(z_0)
-    T* accL = ylds + LG_GE * 64;                                                    // [electron of the group][feature]: Laplacian accumulator
+    T* msum = reinterpret_cast<T*>(lg_smem) + (size_t)wave * (2 * 16 * 64);         // [4a + r][lane]: spin sums of the slot tile; behind it the shared term
     const int e0 = S.grp_e0[g], ng = S.grp_n[g], gsp = S.grp_sp[g];
     const int n_up = S.n_up;
     const T inv_ns = T(1) / T(gsp == 0 ? n_up : S.n_dn);
     const unsigned P = (unsigned)S.P;
     const int D = S.D, N = S.N, NP = S.NP, nch = S.nch, K2 = A.K2;
-    const int nks1 = (A.dbg & 4) ? 8 : A.Kh / 4, nks2 = (A.dbg & 2) ? 2 : K2 / 4;
+    const int nks1 = (GATHER ? A.Kh : A.Kh + nch * K2) / 4, nks2 = K2 / 4;
     const T* Gw = A.Gin + (size_t)w * A.g_ws;              // (uniform bases; the lane's place is a 32-bit byte offset)
     T* Go = A.Gout + (size_t)w * A.g_ws;
     const T* Sw = A.Sb + (size_t)w * Nout * P;
     const T* H2w = A.H2 + (size_t)w * A.h2_ws;
     const T* M2w = A.M2V + (size_t)w * A.m2v_ws;
     T* MPw = A.MEANP + (size_t)w * A.mp_ws + (size_t)g * Nout * P;
+    T* Yw = A.Y + (size_t)w * A.lay_ws;
+    T* ZLw = A.ZLD + (size_t)w * A.lay_ws;
+    T* SSw = A.SSP + ((size_t)w * (P / 16) + t) * A.lay_ws;
     const unsigned gts = (unsigned)A.g_ts;
-    const int ntile = (int)P / 16, nquad = (ng + ST - 1) / ST;
+    const int nquad = (ng + ST - 1) / ST;
     const T rs2 = T(0.70710678118654752440);
     const T inv_n0 = T(1) / T(n_up), inv_n1 = T(1) / T(S.n_dn > 0 ? S.n_dn : 1);
     const unsigned PB = P * (unsigned)sizeof(T);                          // row pitch in bytes
-    // epilogue: this lane owns features n0 + 16a + lr (a = 0..3) and, in slot tile t, the slots 16t + own16(lq, r) (r = 0..3)
-    const unsigned rowb = (unsigned)(n0 + lr) * PB;
+    // epilogue: this lane owns features n0 + 16a + lr (a = 0..3) and the slots 16t + own16(lq, r) (r = 0..3)
+    const unsigned rowb = (unsigned)(n0 + lr) * PB + (unsigned)(16 * t) * (unsigned)sizeof(T);
+    const unsigned featb = (unsigned)(n0 + lr) * (unsigned)sizeof(T);     // (byte offset of feature n0 + lr in the per-electron arrays)
+    const int dl = 16 * t + pos16<T>(lr);                  // slot this lane LOADS in every column tile (A-operand row lr)
+    acc_t msr[NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a) msr[a] = acc_t{0, 0, 0, 0};
+    if (!MSUM_REG) {
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) msum[qq * 64 + lane] = T(0);
+    }
 
-    // the shared term of the NEXT pass is requested at the start of every epilogue (into registers the operand ring has just
-    // released), so a pass starts with its accumulators ready instead of waiting for sixteen loads
-    acc_t Scur[NB];
+    // shared term of this slot tile: loaded ONCE into wave-private LDS; every pass starts its accumulators from there (a
+    // global load at a pass start would sit behind the previous pass's stores in the in-order memory counter)
+    T* sS = msum + 16 * 64;
 #pragma unroll
-    for (int a = 0; a < NB; ++a) Scur[a] = load_own<T>(Sw, rowb + (unsigned)(16 * a) * PB, lq);
-    for (int t = 0; t < ntile; ++t) {
-        const int dl = 16 * t + pos16<T>(lr);              // slot this lane LOADS in every column tile (A-operand row lr)
-        const unsigned tb = (unsigned)(16 * t) * (unsigned)sizeof(T);
-        acc_t msum[NB];                                    // spin sums of the slot tile over the group's electrons
+    for (int a = 0; a < NB; ++a) {
+        const acc_t v = load_own<T>(Sw, rowb + (unsigned)(16 * a) * PB, lq);
 #pragma unroll
-        for (int a = 0; a < NB; ++a) msum[a] = acc_t{0, 0, 0, 0};
-        for (int q = 0; q < nquad; ++q) {
-            const int ecount = ng - ST * q < ST ? ng - ST * q : ST;
-            int iel[ST];                                   // electron of column tile s (dead tiles repeat the last one)
+        for (int r = 0; r < 4; ++r) sS[(4 * a + r) * 64 + lane] = v[r];
+    }
+    // operand ring (PIPE k-steps), software-pipelined ACROSS passes: the first PIPE k-steps of the next pass are requested at
+    // the start of the current pass's epilogue, before any of its stores
+    constexpr int NS = PIPE > 0 ? PIPE : 1;
+    T av[NS][NB], bv[NS][ST];
+    const T* Wl;
+    const T* bp[ST];
+    unsigned binc[ST];                                 // element step per k-step of the pair sub-phases
+    auto pass_pointers = [&](int q) {
+        // (lane ids made opaque: the pointer pieces derived from them are recomputed here -- a few VALU instructions --
+        //  instead of being hoisted, spilled, and reloaded in front of the k-loop, which costs a full vmcnt(0) drain inside it)
+        int lqp = lq, lrp = lr;
+        asm volatile("" : "+v"(lqp), "+v"(lrp));
+        Wl = A.W + (size_t)lqp * Nout + n0 + lrp;
 #pragma unroll
-            for (int s = 0; s < ST; ++s) iel[s] = e0 + (ST * q + s < ng ? ST * q + s : ng - 1);
-            // z = W x + (S + b): the accumulators of all four electrons start at the walker's shared term
-            stamp();                                       // 0: pass start
-            acc_t acc[ST][NB];
+        for (int s = 0; s < ST; ++s) {
+            const int i = e0 + (ST * q + s < ng ? ST * q + s : ng - 1);
+            bp[s] = Gw + ((size_t)i * gts + (size_t)lqp * P + dl);
+        }
+    };
+    // (the scheduling barriers pin "MFMAs of a set, then its reload": moved above them, the reloads of a straight-line block
+    //  need a second copy of the whole ring)
+    auto load_w = [&](int u) {
 #pragma unroll
-            for (int a = 0; a < NB; ++a)
+        for (int a = 0; a < NB; ++a) av[u][a] = Wl[16 * a];
+        Wl += (size_t)4 * Nout;
+    };
+    auto load_g = [&](int u) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(u);
 #pragma unroll
-                for (int s = 0; s < ST; ++s) acc[s][a] = Scur[a];
-            // ---- A operand (jet rows): rows k < Kh from G (phase 1), rows k >= Kh generated from the pair stream (one
-            //      sub-phase per partner spin p: row = (p, k2 = 4 ks + lq)).  Lane kinds in the pair sub-phases: mean lanes
-            //      (slots 0 / 1 and the electron's own three gradient slots, negated), pair-stream lanes (the other gradient
-            //      slots, non-zero only when slot electron jd has spin p), zero lanes (padding).
-            // (lane ids made opaque per pass: the pointer pieces derived from them are then recomputed here -- a few VALU
-            //  instructions -- instead of being hoisted out of the pass loop, spilled, and reloaded in front of the k-loop,
-            //  which costs a full vmcnt(0) drain inside it)
-            int lqp = lq, lrp = lr;
-            asm volatile("" : "+v"(lqp), "+v"(lrp));
-            const T* Wl = A.W + (size_t)lqp * Nout + n0 + lrp;
-            const T* bp[ST];
-            unsigned binc[ST];                             // element step per k-step of the pair sub-phases
+        for (int s = 0; s < ST; ++s) { bv[u][s] = *bp[s]; bp[s] += (size_t)4 * P; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_m = [&](int u) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(u);
 #pragma unroll
-            for (int s = 0; s < ST; ++s) bp[s] = Gw + ((size_t)iel[s] * gts + (size_t)lqp * P + dl);
-            // Pair sub-phase p (partner spin p): B-operand row (p, k2 = 4 ks + lq) of electron i is, per slot,
-            //   slots 0 / 1:              + sum_j value / Laplacian            (M2V, signed sums)
-            //   own gradient slots:       - sum_j d/dr                          (M2V)
-            //   slot (j, c), j != i:      H2[k2][1+c][i*N+j] if spin(j) == p, else 0   (lanes of the other spin read a zero word)
-            //   padding:                  0
-            // all times 1 / n_p, which multiplies the WEIGHT operand of the sub-phase instead (one factor per row).
-            // (everything is computed here from opaque copies of the lane ids: hoisted in front of the G loop these pieces are
-            //  spilled and their reload drains the operand ring)
-            auto to_pairs = [&](int p) {
-                int lq2 = lq, lr2 = lr;
-                asm volatile("" : "+v"(lq2), "+v"(lr2));
-                const int d2 = 16 * t + pos16<T>(lr2);
-                const bool g2 = d2 >= 2 && d2 < D;
-                const int j2 = g2 ? (d2 - 2) / 3 : -1, c2 = g2 ? (d2 - 2) - 3 * j2 : 0;
-                const bool jp = (j2 >= n_up ? 1 : 0) == p;
+        for (int s = 0; s < ST; ++s) { bv[u][s] = *bp[s]; bp[s] += (size_t)binc[s]; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    pass_pointers(0);
+    if (PIPE > 0 && !GATHER) {
 #pragma unroll
-                for (int s = 0; s < ST; ++s) {
-                    const int i = iel[s];
-                    const bool own = g2 && j2 == i, pair = g2 && j2 != i, mean = d2 < 2 || own;
-                    const int comp = d2 == 0 ? 0 : (d2 == 1 ? 4 : 1 + c2);
-                    const T* pm = M2w + (((size_t)i * nch + p) * K2 + lq2) * 5 + comp;
-                    const T* ph = H2w + ((size_t)lq2 * 5 + 1 + c2) * NP + (size_t)i * N + (pair ? j2 : 0);
-                    bp[s] = mean ? pm : ((pair && jp) ? ph : A.zero);
-                    binc[s] = mean ? 20u : ((pair && jp) ? 20u * (unsigned)NP : 0u);
+        for (int u = 0; u < NS; ++u) load_g(u);
+    }
+
+    for (int q = 0; q < nquad; ++q) {
+        const int ecount = ng - ST * q < ST ? ng - ST * q : ST;
+        int iel[ST];                                   // electron of column tile s (dead tiles repeat the last one)
+#pragma unroll
+        for (int s = 0; s < ST; ++s) iel[s] = e0 + (ST * q + s < ng ? ST * q + s : ng - 1);
+        // z = W x + (S + b): the accumulators of all four electrons start at the walker's shared term
+        stamp();                                       // 0: pass start
+        acc_t acc[ST][NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+            acc_t v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = sS[(4 * a + r) * 64 + lane];
+#pragma unroll
+            for (int s = 0; s < ST; ++s) acc[s][a] = v;
+        }
+        // Pair sub-phase p (partner spin p): jet row (p, k2 = 4 ks + lq) of electron i is, per slot,
+        //   slots 0 / 1:              + sum_j value / Laplacian            (M2V, signed sums)
+        //   own gradient slots:       - sum_j d/dr                          (M2V)
+        //   slot (j, c), j != i:      H2[k2][1+c][i*N+j] if spin(j) == p, else 0   (lanes of the other spin read a zero word)
+        //   padding:                  0
+        // all times 1 / n_p, which multiplies the WEIGHT operand of the sub-phase instead (one factor per row).
+        auto to_pairs = [&](int p) {
+            int lq2 = lq, lr2 = lr;
+            asm volatile("" : "+v"(lq2), "+v"(lr2));
+            const int d2 = 16 * t + pos16<T>(lr2);
+            const bool g2 = d2 >= 2 && d2 < D;
+            const int j2 = g2 ? (d2 - 2) / 3 : -1, c2 = g2 ? (d2 - 2) - 3 * j2 : 0;
+            const bool jp = (j2 >= n_up ? 1 : 0) == p;
+#pragma unroll
+            for (int s = 0; s < ST; ++s) {
+                const int i = iel[s];
+                const bool own = g2 && j2 == i, pair = g2 && j2 != i, mean = d2 < 2 || own;
+                const int comp = d2 == 0 ? 0 : (d2 == 1 ? 4 : 1 + c2);
+                const T* pm = M2w + (((size_t)i * nch + p) * K2 + lq2) * 5 + comp;
+                const T* ph = H2w + ((size_t)lq2 * 5 + 1 + c2) * NP + (size_t)i * N + (pair ? j2 : 0);
+                bp[s] = mean ? pm : ((pair && jp) ? ph : A.zero);
+                binc[s] = mean ? 20u : ((pair && jp) ? 20u * (unsigned)NP : 0u);
+            }
+        };
+        auto mm = [&](int u) {
+#pragma unroll
+            for (int s = 0; s < ST; ++s)
+#pragma unroll
+                for (int a = 0; a < NB; ++a) acc[s][a] = mfma16(bv[u][s], av[u][a], acc[s][a]);
+        };
+        if (PIPE > 0 && !GATHER) {
+            // all Kh + nch K2 rows from G; the ring was primed by the previous pass (or in front of the loop)
+            stamp();                                   // 1
+            for (int ks = 0; ks + 2 * NS <= nks1; ks += NS) {
+#pragma unroll
+                for (int u = 0; u < NS; ++u) { mm(u); load_g(u); }
+            }
+#pragma unroll
+            for (int u = 0; u < NS; ++u) mm(u);
+        } else {
+            if (q > 0) pass_pointers(q);
+            auto one = [&](bool pairs, T f) {
+                load_w(0);
+#pragma unroll
+                for (int s = 0; s < ST; ++s) { bv[0][s] = *bp[s]; bp[s] += pairs ? (size_t)binc[s] : (size_t)4 * P; }
+                if (pairs) {
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) av[0][a] *= f;
                 }
+                mm(0);
             };
-            if (PIPE > 0) {
-                // operand ring of NS = PIPE k-steps: a set is re-requested right after its MFMAs are issued, i.e. NS - 1 k-steps
-                // (16 MFMAs each) before it is needed again.  With two sets a wave that runs alone on its SIMD (its partner in
-                // the epilogue) waits for memory every k-step; four sets cover the latency, so one wave's epilogue really
-                // runs under the other's MFMAs.  All phase changes are straight-line code: every load is unconditional.
-                constexpr int NS = PIPE > 0 ? PIPE : 1;
-                T av[NS][NB], bv[NS][ST];
-                auto load_w = [&](int u) {
-#pragma unroll
-                    for (int a = 0; a < NB; ++a) av[u][a] = Wl[16 * a];
-                    Wl += (size_t)4 * Nout;
-                };
-                auto load_g = [&](int u) {
-                    load_w(u);
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) { bv[u][s] = *bp[s]; bp[s] += (size_t)4 * P; }
-                };
-                auto load_m = [&](int u) {
-                    load_w(u);
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) { bv[u][s] = *bp[s]; bp[s] += (size_t)binc[s]; }
-                };
-                auto mm = [&](int u) {
-#pragma unroll
-                    for (int s = 0; s < ST; ++s)
-#pragma unroll
-                        for (int a = 0; a < NB; ++a) acc[s][a] = mfma16(bv[u][s], av[u][a], acc[s][a]);
-                };
-                // (w_scaled: the sets in flight carry weights of pair sub-phase p: times 1 / n_p)
-                auto mm_w = [&](int u, T f) {
-#pragma unroll
-                    for (int a = 0; a < NB; ++a) av[u][a] *= f;
-                    mm(u);
-                };
-#pragma unroll
-                for (int u = 0; u < NS; ++u) load_g(u);
-                stamp();                                   // 1: accumulators set, first operands landed (the stamp waits)
-                for (int ks = 0; ks + 2 * NS <= nks1; ks += NS) {
-#pragma unroll
-                    for (int u = 0; u < NS; ++u) { mm(u); load_g(u); }
-                }
-                stamp();                                   // 2: G rows done
-                to_pairs(0);
-#pragma unroll
-                for (int u = 0; u < NS; ++u) { mm(u); load_m(u); }           // last NS k-steps of G; first NS of the pair rows
-                for (int ks = 0; ks + 2 * NS <= nks2; ks += NS) {
-#pragma unroll
-                    for (int u = 0; u < NS; ++u) { mm_w(u, inv_n0); load_m(u); }
-                }
-                if (nch == 2) {
-                    to_pairs(1);
-#pragma unroll
-                    for (int u = 0; u < NS; ++u) { mm_w(u, inv_n0); load_m(u); }      // last NS of spin 0; first NS of spin 1
-                    for (int ks = 0; ks + 2 * NS <= nks2; ks += NS) {
-#pragma unroll
-                        for (int u = 0; u < NS; ++u) { mm_w(u, inv_n1); load_m(u); }
-                    }
-#pragma unroll
-                    for (int u = 0; u < NS; ++u) mm_w(u, inv_n1);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < NS; ++u) mm_w(u, inv_n0);
-                }
-                stamp();                                   // 3: pair rows done
-            } else {
-                T av[NB], bv[ST];
-                auto one = [&](bool pairs, T f) {
-#pragma unroll
-                    for (int a = 0; a < NB; ++a) av[a] = Wl[16 * a];
-                    Wl += (size_t)4 * Nout;
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) { bv[s] = *bp[s]; bp[s] += pairs ? (size_t)binc[s] : (size_t)4 * P; }
-                    if (pairs) {
-#pragma unroll
-                        for (int a = 0; a < NB; ++a) av[a] *= f;
-                    }
-#pragma unroll
-                    for (int s = 0; s < ST; ++s)
-#pragma unroll
-                        for (int a = 0; a < NB; ++a) acc[s][a] = mfma16(bv[s], av[a], acc[s][a]);
-                };
-                for (int ks = 0; ks < nks1; ++ks) one(false, T(1));
+            for (int ks = 0; ks < nks1; ++ks) one(false, T(1));
+            if (GATHER) {
                 to_pairs(0);
                 for (int ks = 0; ks < nks2; ++ks) one(true, inv_n0);
                 if (nch == 2) {
@@ -372,123 +357,135 @@ __global__ void __launch_bounds__(256, WPS) k_layer_group(SysDev<T> S, LayerArgs
                     for (int ks = 0; ks < nks2; ++ks) one(true, inv_n1);
                 }
             }
-            // ---- epilogue of the pass, one electron (column tile) after the other: tanh chain rule, residual, store, spin sums
-            // residual rows requested two electrons ahead of their use (the registers of a finished electron's accumulators
-            // take the next request): the memory latency is paid once per pass, not once per electron
-            acc_t hvall[ST][NB];
-            auto fetch_res = [&](int s) {
-                const unsigned gb = (unsigned)iel[s] * gts * (unsigned)sizeof(T) + rowb + tb;
-#pragma unroll
-                for (int a = 0; a < NB; ++a) hvall[s][a] = load_own<T>(Gw, gb + (unsigned)(16 * a) * PB, lq);
-            };
-            if (RES) { fetch_res(0); if (ST > 1) fetch_res(1); }
-#pragma unroll
-            for (int s = 0; s < ST; ++s) {
-                if (s >= ecount) continue;
-                if (A.dbg & 1) {                           // (timing experiment: keep the accumulators alive, nothing else)
-                    T v = 0;
-#pragma unroll
-                    for (int a = 0; a < NB; ++a) v += acc[s][a][0] + acc[s][a][1] + acc[s][a][2] + acc[s][a][3];
-                    if (v == T(12345.678)) at_b<T>(Go, rowb) = v;
-                    continue;
-                }
-                const int el = ST * q + s;
-                T* yl = ylds + el * 64;
-                T* al = accL + el * 64;
-                const unsigned gb = (unsigned)iel[s] * gts * (unsigned)sizeof(T) + rowb + tb;      // byte offset of (electron, feature n0 + lr, slot d0)
-                if (t == 0) {
-                    // value slot = (lane row 0, register 0): spread the 64 pre-activations over the lanes, ONE tanh, keep y per feature
-                    if (lq == 0) {
-#pragma unroll
-                        for (int a = 0; a < NB; ++a) yl[16 * a + lr] = acc[s][a][0];
-                    }
-                    const T y = ds_tanh(yl[lane]);
-                    yl[lane] = y;
-                }
-                T y[NB], d1[NB], ss[NB];
-#pragma unroll
-                for (int a = 0; a < NB; ++a) {
-                    y[a] = yl[16 * a + lr];
-                    d1[a] = 1 - y[a] * y[a];
-                }
-#pragma unroll
-                for (int a = 0; a < NB; ++a) {
-                    acc_t o;
-                    T sq = T(0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const T z = acc[s][a][r];
-                        const int d = 16 * t + own16<T>(lq, r);
-                        sq += (d >= 2 && d < D) ? z * z : T(0);
-                        o[r] = d1[a] * z;
-                    }
-                    if (t == 0 && lq == 0) o[0] = y[a];
-                    if (RES) o = (hvall[s][a] + o) * rs2;
-                    ss[a] = rows4_sum(sq);
-                    msum[a] += o;
-                    const unsigned off = gb + (unsigned)(16 * a) * PB;
-                    if (t == 0) {
-                        // (the Laplacian slot -- lane row 0, register 1 -- is written by the final step)
-                        at_b<T>(Go, off + own_off0<T>(lq)) = o[0];
-                        if (lq != 0) at_b<T>(Go, off + own_off0<T>(lq) + (unsigned)sizeof(T)) = o[1];
-                        typedef typename Half2<T>::type h2;
-                        at_b<h2>(Go, off + own_off1<T>(lq)) = h2{o[2], o[3]};
-                    } else
-                        store_own<T>(Go, off, lq, o, true);
-                }
-                // Laplacian accumulator of the electron's features 16a + lr, kept by lane row 0:  y' z_L + y'' sum_d z_d^2
-                if (lq == 0) {
-#pragma unroll
-                    for (int a = 0; a < NB; ++a) {
-                        const T d2 = -2 * y[a] * d1[a];
-                        const T base = t == 0 ? d1[a] * acc[s][a][1] : al[16 * a + lr];
-                        al[16 * a + lr] = base + d2 * ss[a];
-                    }
-                }
-                if (RES && s + 2 < ST) fetch_res(s + 2);
-                if (s == (ecount > 1 ? 1 : 0)) {
-                    // shared term of the next pass (same slot tile, or the next one after the last quad; the very last request
-                    // repeats the current tile and is dropped), into registers of finished accumulators
-                    const int tn = q + 1 < nquad ? t : (t + 1 < ntile ? t + 1 : t);
-                    unsigned so = rowb + (unsigned)(16 * tn) * (unsigned)sizeof(T);
-                    asm volatile("" : "+v"(so));
-#pragma unroll
-                    for (int a = 0; a < NB; ++a) Scur[a] = load_own<T>(Sw, so + (unsigned)(16 * a) * PB, lq);
-                }
-                stamp();                                   // 4..7: electron s done
-            }
         }
-        // partial spin mean of this slot tile over the group's electrons
+        stamp();                                       // 2: products done
+        // ---- epilogue of the pass, one electron (column tile) after the other.  All loads of an electron are requested before
+        //      its first store (loads and stores retire through one counter: a load behind a store waits for the store's ack).
+        acc_t hv[2][NB];
+        T yv[2][NB];
+        auto fetch = [&](int s) {
+            const unsigned gb = (unsigned)iel[s] * gts * (unsigned)sizeof(T) + rowb;
+            const unsigned yb = (unsigned)iel[s] * (unsigned)Nout * (unsigned)sizeof(T) + featb;
 #pragma unroll
-        for (int a = 0; a < NB; ++a) {
-            const unsigned off = rowb + tb + (unsigned)(16 * a) * PB;
-            const acc_t m = msum[a] * inv_ns;
-            if (t == 0) {
-                at_b<T>(MPw, off + own_off0<T>(lq)) = m[0];
-                if (lq != 0) at_b<T>(MPw, off + own_off0<T>(lq) + (unsigned)sizeof(T)) = m[1];
-                typedef typename Half2<T>::type h2;
-                at_b<h2>(MPw, off + own_off1<T>(lq)) = h2{m[2], m[3]};
-            } else
-                store_own<T>(MPw, off, lq, m, false);
+            for (int a = 0; a < NB; ++a) {
+                if (RES) hv[s & 1][a] = load_own<T>(Gw, gb + (unsigned)(16 * a) * PB, lq);
+                if (t != 0) yv[s & 1][a] = at_b<T>(Yw, yb + (unsigned)(16 * a) * (unsigned)sizeof(T));
+            }
+        };
+        if (PIPE > 0 && !GATHER && q + 1 < nquad) {
+            pass_pointers(q + 1);
+#pragma unroll
+            for (int u = 0; u < NS; ++u) load_g(u);
+        }
+        fetch(0);
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            if (s >= ecount) continue;
+            if (s + 1 < ST) fetch(s + 1);
+            const unsigned gb = (unsigned)iel[s] * gts * (unsigned)sizeof(T) + rowb;      // (electron, feature n0 + lr, first slot of the tile)
+            const unsigned yb = (unsigned)iel[s] * (unsigned)Nout * (unsigned)sizeof(T) + featb;
+            T y[NB], d1[NB];
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                if (t == 0) {
+                    // value slot = (lane row 0, register 0): tanh in lane row 0, handed to the other rows by a row sum with zeros
+                    const T yy = lq == 0 ? ds_tanh(acc[s][a][0]) : T(0);
+                    y[a] = rows4_sum(yy);
+                } else
+                    y[a] = yv[s & 1][a];
+                d1[a] = 1 - y[a] * y[a];
+            }
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                acc_t o;
+                T sq = T(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const T z = acc[s][a][r];
+                    const int d = 16 * t + own16<T>(lq, r);
+                    sq += (d >= 2 && d < D) ? z * z : T(0);
+                    o[r] = d1[a] * z;
+                }
+                if (t == 0 && lq == 0) o[0] = y[a];
+                if (RES) o = (hv[s & 1][a] + o) * rs2;
+                const T ss = (A.dbg & 128) ? sq : rows4_sum(sq);
+                if (MSUM_REG) msr[a] += o;
+                else if (!(A.dbg & 64)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) msum[(4 * a + r) * 64 + lane] += o[r];      // spin sum of the slot tile (wave-private LDS)
+                }
+                const unsigned off = gb + (unsigned)(16 * a) * PB;
+                if (A.dbg & 256) {
+                    if (o[0] == T(12345.678)) at_b<T>(Go, off) = o[1] + o[2] + o[3];
+                } else if (t == 0) {
+                    // (the Laplacian slot -- lane row 0, register 1 -- is written by k_layer_fin)
+                    at_b<T>(Go, off + own_off0<T>(lq)) = o[0];
+                    if (lq != 0) at_b<T>(Go, off + own_off0<T>(lq) + (unsigned)sizeof(T)) = o[1];
+                    typedef typename Half2<T>::type h2;
+                    at_b<h2>(Go, off + own_off1<T>(lq)) = h2{o[2], o[3]};
+                } else
+                    store_own<T>(Go, off, lq, o, true);
+                if (lq == 0 && !(A.dbg & 512)) {
+                    const unsigned fo = yb + (unsigned)(16 * a) * (unsigned)sizeof(T);
+                    at_b<T>(SSw, fo) = ss;
+                    if (t == 0) {
+                        at_b<T>(Yw, fo) = y[a];
+                        at_b<T>(ZLw, fo) = d1[a] * acc[s][a][1];
+                    }
+                }
+            }
+            stamp();                                   // 3..6: electron s done (stores retired)
         }
     }
-    // ---- Laplacian slot: lane <-> feature n0 + lane
-    {
-        const unsigned nP = (unsigned)(n0 + lane) * PB + (unsigned)sizeof(T);
-        T sumL = 0;
-        for (int e = 0; e < ng; ++e) {
-            const unsigned off = (unsigned)(e0 + e) * gts * (unsigned)sizeof(T) + nP;
-            T oL = accL[e * 64 + lane];
-            if (RES) oL = (at_b<T>(Gw, off) + oL) * rs2;
-            at_b<T>(Go, off) = oL;
-            sumL += oL;
-        }
-        at_b<T>(MPw, nP) = sumL * inv_ns;
+    // partial spin mean of this slot tile over the group's electrons
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+        const unsigned off = rowb + (unsigned)(16 * a) * PB;
+        acc_t m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[r] = (MSUM_REG ? msr[a][r] : msum[(4 * a + r) * 64 + lane]) * inv_ns;
+        if (t == 0) {
+            at_b<T>(MPw, off + own_off0<T>(lq)) = m[0];
+            if (lq != 0) at_b<T>(MPw, off + own_off0<T>(lq) + (unsigned)sizeof(T)) = m[1];
+            typedef typename Half2<T>::type h2;
+            at_b<h2>(MPw, off + own_off1<T>(lq)) = h2{m[2], m[3]};
+        } else
+            store_own<T>(MPw, off, lq, m, false);
     }
     if (A.clk && wave == 0 && lane == 0) {
         atomicAdd(A.clk, (unsigned long long)(clock64() - clk_c0));
         atomicAdd(A.clk + 1, (unsigned long long)(wall_clock64() - clk_r0));
     }
+}
+
+// Laplacian slot of the layer output:  o_L = y' z_L + y'' sum_d z_d^2  (sum over ALL gradient slots: the slot-tile partials of
+// k_layer_unit, added in tile order), residual, and its partial spin mean.  grid (n_groups, walkers), block = Nout threads.
+template <typename T, bool RES>
+__global__ void __launch_bounds__(1024) k_layer_fin(SysDev<T> S, LayerArgs<T> A) {
+    const int g = blockIdx.x, w = blockIdx.y, n = threadIdx.x;
+    if (n >= A.Nout) return;
+    const int e0 = S.grp_e0[g], ng = S.grp_n[g], P = S.P, ntile = P / 16;
+    const T inv_ns = T(1) / T(S.grp_sp[g] == 0 ? S.n_up : S.n_dn);
+    const T rs2 = T(0.70710678118654752440);
+    const T* Yw = A.Y + (size_t)w * A.lay_ws;
+    const T* ZLw = A.ZLD + (size_t)w * A.lay_ws;
+    const T* SSw = A.SSP + (size_t)w * ntile * A.lay_ws;
+    const T* Gw = A.Gin + (size_t)w * A.g_ws;
+    T* Go = A.Gout + (size_t)w * A.g_ws;
+    T sumL = 0;
+    for (int e = 0; e < ng; ++e) {
+        const int i = e0 + e;
+        const size_t fo = (size_t)i * A.Nout + n;
+        const T y = Yw[fo], d1 = 1 - y * y, d2 = -2 * y * d1;
+        T ss = 0;
+        for (int t = 0; t < ntile; ++t) ss += SSw[(size_t)t * A.lay_ws + fo];
+        T oL = ZLw[fo] + d2 * ss;
+        const size_t go = (size_t)i * A.g_ts + (size_t)n * P + 1;
+        if (RES) oL = (Gw[go] + oL) * rs2;
+        Go[go] = oL;
+        sumL += oL;
+    }
+    A.MEANP[(size_t)w * A.mp_ws + ((size_t)g * A.Nout + n) * P + 1] = sumL * inv_ns;
 }
 
 }  // namespace ds

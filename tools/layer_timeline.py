@@ -30,8 +30,8 @@ t = np.array(buf[:], dtype=np.int64)
 t = t[t > 0]
 print('stamps:', len(t), ' (the last hidden-layer launch overwrites the earlier ones)')
 d = np.diff(t)
-per = 8                                           # stamps per pass: start, ready, G done, pairs done, 4 electrons
-names = ['start->ready', 'G rows', 'pair rows', 'e0', 'e1', 'e2', 'e3', 'next pass']
+per = 7                                           # stamps per pass: start, ready, products done, 4 electrons
+names = ['start->ready', 'products', 'e0', 'e1', 'e2', 'e3', 'next pass']
 npass = len(t) // per
 for p in range(min(npass, 16)):
     seg = d[p * per:(p + 1) * per]

@@ -11,7 +11,9 @@ from collections import defaultdict
 
 root = sys.argv[1]
 CALIB_BYTES = 8 * (1 << 28)
-out = {'calib_bytes_each_way': CALIB_BYTES, 'walkers_per_launch': 1024, 'kernels': {}}
+out = {'calib_bytes_each_way': CALIB_BYTES, 'walkers_per_launch': 1024, 'system': os.environ.get('PMC_SYSTEM', 'bcc_li'),
+       'dtype': os.environ.get('PMC_DTYPE', 'f64'), 'kernels': {}}
+dur = defaultdict(list)          # kernel durations inside the profile passes (ms): bench.py only trusts the counters when they agree with its own
 raw = {}
 for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
     files = glob.glob(os.path.join(root, counter, '**', '*counter_collection.csv'), recursive=True)
@@ -23,6 +25,8 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             name = row['Kernel_Name'].split('(')[0].replace('void ', '')
             tot[name] += float(row['Counter_Value'])
             cnt[name] += 1
+            if row.get('Start_Timestamp') and row.get('End_Timestamp'):
+                dur[name].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) * 1e-6)
     raw[counter] = {k: (tot[k], cnt[k]) for k in tot}
     calib = [v for k, v in raw[counter].items() if 'k_calib_copy' in k]
     out[counter + '_units_per_byte'] = (calib[0][0] / calib[0][1]) / CALIB_BYTES if calib else None
@@ -35,5 +39,7 @@ for name in sorted(set(raw['FETCH_SIZE']) | set(raw['WRITE_SIZE'])):
             t, c = raw[counter][name]
             e[key + '_bytes_per_launch'] = t / c / out[counter + '_units_per_byte']
             e['launches'] = c
+    if dur.get(name):
+        e['avg_launch_ms'] = sum(dur[name]) / len(dur[name])
     out['kernels'][name] = e
 print(json.dumps(out, indent=1))
