@@ -79,6 +79,7 @@ struct ds_system {
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     bool lg_gather = false;           // DS_LG_GATHER=1: hidden layers gather the pair-mean rows too (layer 0 always does)
+    int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
     int lg_ring = 2;                  // DS_LG_RING: operand ring depth of k_layer_group (2 or 4)
     int lg_dbg = 0;                   // DS_LG_DBG (timing experiments, wrong results)
     size_t lg_pad_lds = 0;            // DS_LG_PAD_LDS (experiment): extra dynamic LDS per workgroup of k_layer_group
@@ -521,7 +522,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
                 if (res) {
                     ds::OrbEpi<T> oe_clk{};
-                    if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) oe_clk.clk = s->clk_dev;
+                    if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { oe_clk.clk = s->clk_dev; oe_clk.dbg = s->lg_dbg; }
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
                                        (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), oe_clk);
@@ -1347,6 +1348,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     if (const char* e = getenv("DS_LG_PAD_LDS")) s->lg_pad_lds = (size_t)atol(e);
     if (const char* e = getenv("DS_LG_DBG")) s->lg_dbg = atoi(e);
     if (const char* e = getenv("DS_LG_RING")) s->lg_ring = atoi(e);
+    if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::max<int64_t>(1, atol(e));
     if (const char* e = getenv("DS_LG_GATHER")) s->lg_gather = atoi(e) != 0;
     if (s->n_streams == 2) {
         bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -1398,10 +1400,12 @@ int ds_param_layout(const ds_system* s, ds_param_block* blocks, int max_blocks) 
 int64_t ds_workspace_bytes(const ds_system* s, int64_t B) {
     if (!s) return -1;
     const int64_t esz = s->dtype == 0 ? 8 : 4;
-    // walkers are processed in chunks: at most 1024 per chunk and at most ~24 GiB of scratch (large cells need
-    // hundreds of MB per walker: 96 electrons f32 = 0.2 GB)
-    const int64_t budget = (int64_t)24 << 30;
-    int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 1024);
+    // walkers are processed in chunks: at most 4096 per chunk and at most ~80 GiB of scratch of the 288 GB (large cells need
+    // hundreds of MB per walker: 96 electrons f32 = 0.2 GB).  One 4096-walker pass instead of four 1024-walker passes is
+    // 1.5-2 % faster (fewer kernel tails) with bit-identical energies (tools/chunk_sweep.py); DS_CHUNK_WALKERS (read at create) overrides the cap.
+    const int64_t budget = (int64_t)80 << 30;
+    const int64_t cap = s->chunk_cap;
+    int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), cap);
     chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, budget / ((int64_t)s->ws.per_walker * esz)));
     int64_t groups = std::min<int64_t>((std::max<int64_t>(B, 1) + ds::PV - 1) / ds::PV, 64);
     groups = std::max<int64_t>(1, std::min<int64_t>(groups, budget / ((int64_t)s->wsv.per_walker * esz)));

@@ -31,6 +31,7 @@ template <typename T> struct OrbEpi {
     // optional in-kernel clock probe (hidden layers, EPI = 2, while profiling): wave 0 of every workgroup adds its shader-clock
     // cycles (s_memtime) to clk[0] and its constant-rate 100 MHz ticks (s_memrealtime) to clk[1]
     unsigned long long* clk;
+    int dbg;                        // DS_LG_DBG & 32 (kernel development): one wave also writes phase stamps to clk[2 + i]
 };
 
 // Residual stash (EPI = 2 / 4): the residual rows of a layer are rows n0..n0+16*NB-1 of the SAME tile the wave streams as
@@ -103,6 +104,10 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     if (n0 >= Nout) return;                      // column blocks beyond Nout (grid.z rounds up)
     long long clk_c0 = 0, clk_r0 = 0;
     if (EPI == 2 && oe.clk && wave == 0) { clk_c0 = clock64(); clk_r0 = wall_clock64(); }
+    unsigned long long* tl = (EPI == 2 && oe.clk && (oe.dbg & 32) && blockIdx.x == gridDim.x / 8 && blockIdx.y == gridDim.y / 2 && wave == 0 && lane == 0) ? oe.clk + 2 : nullptr;
+    int n_tl = 0;
+    auto stamp = [&]() { if (EPI == 2 && tl) { __builtin_amdgcn_s_waitcnt(0); tl[n_tl++] = (unsigned long long)clock64(); } };
+    stamp();
     const T* Xp;
     const T* Wp;
     int nks;
@@ -176,6 +181,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         // waits stay partial (vmcnt(27)): a conditional reload would force a full drain at the loop head
 #pragma unroll
         for (int u = 0; u < NSET; ++u) load_set(u);       // (nks >= 4 >= NSET)
+        stamp();
         int ks = 0;
         if (NSET == 4) {
             for (; ks + 4 < nks; ks += 4) {
@@ -205,6 +211,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         // short contractions (layer 0: K = 12, 8): one set, no ring
         for (int ks = 0; ks < nks; ++ks) { load_set(0); step(0, ks); }
     }
+    stamp();
     if (EPI == 0 || EPI == 6 || EPI == 7) {
         // EPI 6 / 7: the shared term of a layer, stored WITH the layer's bias (6: on the value slot of the jets,
         // 7: on every walker column of the value chain), so the consuming GEMM starts its accumulators at S + b
@@ -355,6 +362,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
             }
         }
     }
+    stamp();
     if (EPI == 2 && oe.clk && wave == 0 && lane == 0) {
         atomicAdd(oe.clk, (unsigned long long)(clock64() - clk_c0));
         atomicAdd(oe.clk + 1, (unsigned long long)(wall_clock64() - clk_r0));

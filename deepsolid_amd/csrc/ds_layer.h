@@ -167,8 +167,8 @@ template <typename T, typename B> __device__ __forceinline__ void store_own(B* b
 // grid (nt * n_groups * column blocks, walkers): workgroup = (slot tile t0 + ., electron group, 256 features), four waves.
 // GATHER: the rows k >= Kh come from the pair stream (above); otherwise all Kh + nch K2 rows are read from G (k_m2_expand ran).
 // ST = electrons (column tiles) per pass: 4, or 3 (leaves registers for a four-deep ring and the spin sums).
-template <typename T, bool RES, int PIPE, bool GATHER, int ST = 4>
-__global__ void __launch_bounds__(256, 2) k_layer_unit(SysDev<T> S, LayerArgs<T> A) {
+template <typename T, bool RES, int PIPE, bool GATHER, int ST = 4, int WPS = 2>
+__global__ void __launch_bounds__(256, WPS) k_layer_unit(SysDev<T> S, LayerArgs<T> A) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int NB = 4;
     constexpr bool MSUM_REG = ST < 4;                      // spin sums in registers when the accumulators leave room

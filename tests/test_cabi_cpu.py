@@ -110,3 +110,43 @@ def test_philox_known_answers_and_moments():
     z = np.concatenate([np.sqrt(-2 * np.log(u1)) * np.cos(2 * np.pi * u2), np.sqrt(-2 * np.log(u1)) * np.sin(2 * np.pi * u2)])
     assert abs(z.mean()) < 0.02 and abs(z.var() - 1) < 0.03 and abs((z ** 4).mean() - 3) < 0.15
     assert abs(u2.mean() - 0.5) < 0.01
+
+
+def test_shape_limits_are_rejected_at_create():
+    """Every shape the kernels cannot run is refused by ds_system_create itself (check_arch runs before any device
+    allocation, so this needs no GPU): a handle that was created never fails at its first launch.  The supported set is
+    documented in DESIGN.md section 1: determinant matrices up to 64 x 64, N <= 52 or 96..100 electrons (jet-slot tiles
+    1..10 and 19), hidden_single multiples of 64 up to 1024, hidden_double 16 or 32, up to 32 determinants."""
+    import ctypes as C
+    from deepsolid_amd import _lib
+    lib = _lib.load()
+
+    def desc(**kw):
+        d = _lib.SystemDesc()
+        d.dtype, d.n_up, d.n_dn, d.n_atoms_prim, d.n_sym, d.n_layers, d.n_det = 0, 2, 2, 1, 3, 3, 8
+        for i in range(3):
+            d.hidden_single[i], d.hidden_double[i] = 256, 32
+        for k, v in kw.items():
+            if isinstance(v, (list, tuple)):
+                for i, x in enumerate(v):
+                    getattr(d, k)[i] = x
+            else:
+                setattr(d, k, v)
+        return d
+
+    def err(**kw):
+        h = C.c_void_p()
+        rc = lib.ds_system_create(C.byref(desc(**kw)), C.byref(h))
+        assert rc != 0, kw
+        return lib.ds_last_error().decode()
+
+    assert 'larger than 64' in err(n_up=65, n_dn=0)
+    assert 'larger than 64' in err(n_up=40, n_dn=30, full_det=1)
+    assert 'jet-slot tiles' in err(n_up=30, n_dn=30)                      # N = 60: 12 slot tiles, no kernel instance
+    assert 'hidden_single' in err(hidden_single=[256, 200, 256])
+    assert 'hidden_single' in err(hidden_single=[2048, 256, 256])
+    assert 'hidden_double' in err(hidden_double=[32, 24, 32])
+    assert 'n_det' in err(n_det=33)
+    assert 'n_up' in err(n_up=0)
+    assert 'n_dn' in err(n_dn=-1)
+    assert 'tri' in err(distance_type=1, envelope_type=2)
