@@ -522,6 +522,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
                 if (res) {
                     ds::OrbEpi<T> oe_clk{};
+                    oe_clk.dbg = s->lg_dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
                     if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { oe_clk.clk = s->clk_dev; oe_clk.dbg = s->lg_dbg; }
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
                                        blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],

@@ -128,7 +128,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
     T* stash = reinterpret_cast<T*>(gemm_smem) + (size_t)wave * (NA * 4 * ST * 64);
     acc_t acc[NB][ST];
-    if (LAYER) {
+    if (LAYER && !(EPI == 2 && DS_EXP(oe.dbg & 2))) {
         // z = W x + (S + b): the accumulators start at the shared spin-mean term, which already carries the bias
         // (EPI = 6 / 7 below, k_shared_term); these loads overlap the first operand loads
         const T* Sp0 = Sb + (size_t)w * Nout * P + lr;
@@ -284,6 +284,14 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                     }
                 }
             }
+    } else if (EPI == 2 && DS_EXP(oe.dbg & 1)) {
+        // (timing experiment: no epilogue)
+        T v = 0;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int s = 0; s < ST; ++s) v += acc[a][s][0] + acc[a][s][1] + acc[a][s][2] + acc[a][s][3];
+        if (v == T(12345.678)) Z[0] = v;
     } else {
         // Z here is the next layer's G: [walker][tile][x_tile_stride / P rows][P] (same geometry as X)
         const T rs2 = T(0.70710678118654752440);

@@ -408,14 +408,14 @@ __global__ void __launch_bounds__(256, WPS) k_layer_unit(SysDev<T> S, LayerArgs<
                 }
                 if (t == 0 && lq == 0) o[0] = y[a];
                 if (RES) o = (hv[s & 1][a] + o) * rs2;
-                const T ss = (A.dbg & 128) ? sq : rows4_sum(sq);
+                const T ss = DS_EXP(A.dbg & 128) ? sq : rows4_sum(sq);
                 if (MSUM_REG) msr[a] += o;
-                else if (!(A.dbg & 64)) {
+                else if (!DS_EXP(A.dbg & 64)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) msum[(4 * a + r) * 64 + lane] += o[r];      // spin sum of the slot tile (wave-private LDS)
                 }
                 const unsigned off = gb + (unsigned)(16 * a) * PB;
-                if (A.dbg & 256) {
+                if DS_EXP(A.dbg & 256) {
                     if (o[0] == T(12345.678)) at_b<T>(Go, off) = o[1] + o[2] + o[3];
                 } else if (t == 0) {
                     // (the Laplacian slot -- lane row 0, register 1 -- is written by k_layer_fin)
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256, WPS) k_layer_unit(SysDev<T> S, LayerArgs<
                     at_b<h2>(Go, off + own_off1<T>(lq)) = h2{o[2], o[3]};
                 } else
                     store_own<T>(Go, off, lq, o, true);
-                if (lq == 0 && !(A.dbg & 512)) {
+                if (lq == 0 && !DS_EXP(A.dbg & 512)) {
                     const unsigned fo = yb + (unsigned)(16 * a) * (unsigned)sizeof(T);
                     at_b<T>(SSw, fo) = ss;
                     if (t == 0) {

@@ -265,6 +265,27 @@ def test_per_electron_layer_path_vs_reference_hamiltonian(name, monkeypatch):
     assert np.abs(out['1'] - out['0']).max() < 1e-10 * max(1.0, np.abs(out['0']).max())
 
 
+@pytest.mark.parametrize('groups', ['0', '1'])
+def test_debug_switches_cannot_change_results(groups, monkeypatch):
+    """The kernel-development switches (DS_LG_DBG: skip the epilogue, start the accumulators at zero, shorten the k-loops,
+    ...) exist only in a library built with `make EXP=1`.  In the shipped build they are compiled out: with every bit set
+    the energies of both layer paths are BIT-identical to a run without them (the remaining bits -- clock probe, phase
+    stamps, start skew -- only time things)."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case('bcc_li')
+    dp = dev_params(params)
+    x = torch.as_tensor(fx['x'][:4], device='cuda')
+    monkeypatch.setenv('DS_LAYER_GROUPS', groups)
+    monkeypatch.delenv('DS_LG_DBG', raising=False)
+    ref = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).local_energy(dp, x)[0]
+    monkeypatch.setenv('DS_LG_DBG', str(1 | 2 | 4 | 64 | 128 | 256 | 512))
+    got = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).local_energy(dp, x)[0]
+    assert torch.equal(ref, got)
+    for b in range(4):
+        assert abs(complex(*got[b].tolist()) - fx['ke_ref'][b]) < 1e-9 * max(1.0, abs(fx['ke_ref'][b]))
+
+
 @pytest.mark.parametrize('name,dtype,B', [('bcc_li', torch.float64, 4096 + 3), ('diamond', torch.float32, 1024 + 5)])
 def test_full_batch_tiled_fixture_walkers(name, dtype, B):
     """Parity at the sizes bench.py runs (BASELINE configs 3 and 5): the fixture's reference-executed walkers tiled to a

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Workload for the PMC passes: one calibration copy of known size + one local-energy evaluation of
-1024 bcc-Li walkers (= one launch of every kernel of the chain per layer)."""
+"""Workload for the PMC passes: one calibration copy of known size + three local-energy evaluations of 4096 bcc-Li walkers
+(the bench line's batch = one launch of every kernel of the chain per layer and evaluation; the first evaluation also warms
+the clocks up -- tools/pmc_summarize.py reports the MEDIAN duration of a kernel's launches)."""
 import ctypes as C
 import os
 import sys
@@ -20,7 +21,9 @@ torch.cuda.synchronize()
 cell, klist = systems.build('bcc_li')
 net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **systems.DETNET_DEFAULTS)
 params = net.init(0)
-x = torch.as_tensor(systems.synthetic_walkers(cell, 1024), device='cuda')
-ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(params, x)
-torch.cuda.synchronize()
-print('calib_bytes_each_way', 8 * n, 'walkers', 1024)
+B = int(os.environ.get('PMC_WALKERS', 4096))
+x = torch.as_tensor(systems.synthetic_walkers(cell, B), device='cuda')
+for _ in range(3):
+    ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(params, x)
+    torch.cuda.synchronize()
+print('calib_bytes_each_way', 8 * n, 'walkers', B)

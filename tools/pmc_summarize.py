@@ -11,7 +11,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 CALIB_BYTES = 8 * (1 << 28)
-out = {'calib_bytes_each_way': CALIB_BYTES, 'walkers_per_launch': 1024, 'system': os.environ.get('PMC_SYSTEM', 'bcc_li'),
+out = {'calib_bytes_each_way': CALIB_BYTES, 'walkers_per_launch': int(os.environ.get('PMC_WALKERS', 4096)), 'system': os.environ.get('PMC_SYSTEM', 'bcc_li'),
        'dtype': os.environ.get('PMC_DTYPE', 'f64'), 'kernels': {}}
 dur = defaultdict(list)          # kernel durations inside the profile passes (ms): bench.py only trusts the counters when they agree with its own
 raw = {}
@@ -40,6 +40,6 @@ for name in sorted(set(raw['FETCH_SIZE']) | set(raw['WRITE_SIZE'])):
             e[key + '_bytes_per_launch'] = t / c / out[counter + '_units_per_byte']
             e['launches'] = c
     if dur.get(name):
-        e['avg_launch_ms'] = sum(dur[name]) / len(dur[name])
+        e['avg_launch_ms'] = sorted(dur[name])[len(dur[name]) // 2]          # median over the profile run's launches
     out['kernels'][name] = e
 print(json.dumps(out, indent=1))
