@@ -192,6 +192,14 @@ __global__ void __launch_bounds__(256, WPS) k_layer_unit(SysDev<T> S, LayerArgs<
     auto stamp = [&]() {
         if (tl && n_tl < 1000) { __builtin_amdgcn_s_waitcnt(0); tl[n_tl++] = (unsigned long long)clock64(); }
     };
+    if (DS_EXP(A.dbg & 24)) {
+        // (experiment: start skew of the waves in odd hardware slots (8) or by a hash of the workgroup id (16), A.dbg >> 20 sleeps
+        //  of 8128 cycles -- would the two waves of a SIMD overlap better out of lockstep?)
+        const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));        // HW_ID.wave_id
+        const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, h = (b * 2654435761u) >> 28;
+        const unsigned n = (A.dbg & 16) ? h * (unsigned)(A.dbg >> 20) : ((slot & 1u) ? (unsigned)(A.dbg >> 20) : 0u);
+        for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     extern __shared__ __attribute__((aligned(16))) char lg_smem[];
     T* msum = reinterpret_cast<T*>(lg_smem) + (size_t)wave * (2 * 16 * 64);         // [4a + r][lane]: spin sums of the slot tile; behind it the shared term
     const int e0 = S.grp_e0[g], ng = S.grp_n[g], gsp = S.grp_sp[g];
@@ -199,7 +207,7 @@ __global__ void __launch_bounds__(256, WPS) k_layer_unit(SysDev<T> S, LayerArgs<
     const T inv_ns = T(1) / T(gsp == 0 ? n_up : S.n_dn);
     const unsigned P = (unsigned)S.P;
     const int D = S.D, N = S.N, NP = S.NP, nch = S.nch, K2 = A.K2;
-    const int nks1 = (GATHER ? A.Kh : A.Kh + nch * K2) / 4, nks2 = K2 / 4;
+    const int nks1 = DS_EXP(A.dbg & 4) ? 8 : (GATHER ? A.Kh : A.Kh + nch * K2) / 4, nks2 = K2 / 4;      // (experiment: 8 instead of 80 k-steps)
     const T* Gw = A.Gin + (size_t)w * A.g_ws;              // (uniform bases; the lane's place is a 32-bit byte offset)
     T* Go = A.Gout + (size_t)w * A.g_ws;
     const T* Sw = A.Sb + (size_t)w * Nout * P;
@@ -381,6 +389,13 @@ __global__ void __launch_bounds__(256, WPS) k_layer_unit(SysDev<T> S, LayerArgs<
 #pragma unroll
         for (int s = 0; s < ST; ++s) {
             if (s >= ecount) continue;
+            if (DS_EXP(A.dbg & 1)) {                       // (experiment: keep the accumulators alive, nothing else)
+                T v = 0;
+#pragma unroll
+                for (int a = 0; a < NB; ++a) v += acc[s][a][0] + acc[s][a][1] + acc[s][a][2] + acc[s][a][3];
+                if (v == T(12345.678)) at_b<T>(Go, rowb) = v;
+                continue;
+            }
             if (s + 1 < ST) fetch(s + 1);
             const unsigned gb = (unsigned)iel[s] * gts * (unsigned)sizeof(T) + rowb;      // (electron, feature n0 + lr, first slot of the tile)
             const unsigned yb = (unsigned)iel[s] * (unsigned)Nout * (unsigned)sizeof(T) + featb;
