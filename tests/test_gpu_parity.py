@@ -265,6 +265,28 @@ def test_per_electron_layer_path_vs_reference_hamiltonian(name, monkeypatch):
     assert np.abs(out['1'] - out['0']).max() < 1e-10 * max(1.0, np.abs(out['0']).max())
 
 
+@pytest.mark.parametrize('name', ['lih', 'bcc_li'])
+def test_electron_group_layer_path_float32(name, monkeypatch):
+    """The float32 instantiation of the electron-group layer kernels (DS_LAYER_GROUPS=1; the accumulator <-> slot maps differ
+    from float64): E_kin against the float64 oracle at the float32-rounded walker, tolerance of the default float32 chain
+    (test_float32_chain_vs_float64_oracle: 1e-4 relative), and agreement with the default float32 path to the same."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    p_cpu = onet.params_to_torch(params)
+    x = torch.as_tensor(fx['x'][:2], dtype=torch.float32, device='cuda')
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('DS_LAYER_GROUPS', flag)
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float32)
+        out[flag] = torch.view_as_complex(sysd.local_energy(dp, x)[0].double()).cpu().numpy()
+    for b in range(2):
+        ref = complex(ofl.stages(p_cpu, x[b].cpu().double(), klist, cell, net_kw)['ke'])
+        for flag in ('1', '0'):
+            assert abs(out[flag][b] - ref) < 1e-4 * max(1.0, abs(ref)), (flag, b, out[flag][b], ref)
+
+
 @pytest.mark.parametrize('groups', ['0', '1'])
 def test_debug_switches_cannot_change_results(groups, monkeypatch):
     """The kernel-development switches (DS_LG_DBG: skip the epilogue, start the accumulators at zero, shorten the k-loops,
