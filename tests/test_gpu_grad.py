@@ -192,6 +192,54 @@ def test_training_step_runs_and_lowers_the_energy_estimate():
     assert np.mean(losses[-3:]) < np.mean(losses[:3])
 
 
+def test_training_step_rejects_a_step_with_a_nan_walker():
+    """process.py:303-318 (cfg.debug.check_nan) through the real kernels: one walker with a NaN coordinate makes its local energy
+    NaN, `ds_energy_stats` counts it (n_nonfinite, all-reduced), and the step is DISCARDED before Adam touches anything --
+    parameters, optimiser moments / step count and the walkers come back bit-identical, loss = aux = None.  The next step on
+    finite walkers is applied.  Without check_nan the same step poisons the parameters (the reason it is on in run_training)."""
+    from deepsolid_amd import network as dnet, qmc, train as dtrain
+    fx, cell, klist, net_kw, params = load_case('lih')
+    net = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    slog = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', **net_kw)
+    B = 256
+    loss_fn = dtrain.make_loss(net.apply, None, cell, clip_local_energy=5.0, clip_type='real')
+    real_mcmc = qmc.make_mcmc_step(slog.apply, B, cell.a, steps=3)
+    poison = {'on': True}
+
+    def mcmc(p, d, key, w):
+        d2, pm = real_mcmc(p, d, key, w)
+        if poison['on']:
+            d2 = d2.clone()
+            d2[7, 4] = float('nan')                       # one coordinate of one walker
+        return d2, pm
+
+    init, update = dtrain.adam(2e-3)
+    dp = dev_params(params)
+    state = init(dp)
+    data = torch.as_tensor(systems.synthetic_walkers(cell, B, seed=2), device='cuda')
+    # the statistics kernel sees the bad walker
+    bad = data.clone(); bad[7, 4] = float('nan')
+    _, aux_bad = loss_fn(dp, bad)
+    assert float(aux_bad.n_nonfinite) == 1.0
+    step = dtrain.make_training_step(mcmc, loss_fn, update, check_nan=True)
+    before = [p.clone() for p in leaves(dp)]
+    d1, dp, state, loss, aux, pmove, g = step(0, data, dp, state, 11, 0.1)
+    assert loss is None and aux is None and g is None and d1 is data
+    assert state['count'] == 0 and all(float(m.abs().max()) == 0.0 for m in state['m'])
+    assert all(torch.equal(a, b) for a, b in zip(before, leaves(dp)))
+    poison['on'] = False
+    d2, dp, state, loss, aux, pmove, g = step(1, data, dp, state, 12, 0.1)
+    assert loss is not None and np.isfinite(float(loss)) and state['count'] == 1 and float(aux.n_nonfinite) == 0.0
+    assert any(not torch.equal(a, b) for a, b in zip(before, leaves(dp)))
+    # the reference's default (no check): the poisoned step is applied and the parameters are lost
+    poison['on'] = True
+    dq = dev_params(params)
+    sq = init(dq)
+    plain = dtrain.make_training_step(mcmc, loss_fn, update)
+    _, dq, sq, loss, *_ = plain(0, data, dq, sq, 11, 0.1)
+    assert not all(bool(torch.isfinite(p).all()) for p in leaves(dq))
+
+
 def test_training_loop_writes_stats_and_reference_checkpoints(tmp_path):
     """inference.run_training (process.py:204-383, Adam branch): CSV rows in the reference schema, checkpoints that
     `checkpoint.restore` (reference layout) reads back, parameters updated in place."""
