@@ -99,7 +99,7 @@ CASES = {
                           ke_walkers=4, ke_modes=('for', 'hessian'), grad_walkers=4),
     'bcc_li_twist':  dict(system='bcc_li', seed=16, batch=2, twist=(0.3, 0.0, 0.15), mcmc=False, ke_walkers=2),
     'graphene':      dict(system='graphene', seed=17, batch=4, mcmc=False, ke_walkers=4, ke_modes=('for', 'hessian')),
-    'diamond':       dict(system='diamond', seed=18, batch=2, mcmc=False, ke_walkers=2),
+    'diamond':       dict(system='diamond', seed=18, batch=4, mcmc=False, ke_walkers=4),
     'lih_fulldet':   dict(system='lih', seed=19, batch=3, net_kw=dict(full_det=True), mcmc=False, gradfd_walkers=2,
                           ke_walkers=3, grad_walkers=3),
     'lih_tri':       dict(system='lih', seed=20, batch=3, net_kw=dict(distance_type='tri'), mcmc=False, gradfd_walkers=2,

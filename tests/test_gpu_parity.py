@@ -13,7 +13,7 @@ from oracle import hamiltonian as oham
 from oracle import network as onet
 from oracle.testing import CASES
 
-from common import load_case, oracle_net, tt
+from common import float32_budget, float32_tolerance, load_case, oracle_net, tt
 
 pytestmark = pytest.mark.gpu
 
@@ -311,9 +311,10 @@ def test_debug_switches_cannot_change_results(groups, monkeypatch):
 @pytest.mark.parametrize('name,dtype,B', [('bcc_li', torch.float64, 4096 + 3), ('diamond', torch.float32, 1024 + 5)])
 def test_full_batch_tiled_fixture_walkers(name, dtype, B):
     """Parity at the sizes bench.py runs (BASELINE configs 3 and 5): the fixture's reference-executed walkers tiled to a
-    full batch with a ragged last chunk.  Every copy must equal ke_ref (1e-9 Ha relative in float64; the float32 budget
-    of test_float32_chain_vs_float64_oracle for diamond) and all copies of a walker must be BIT-identical wherever they
-    sit in the 1024-walker chunks -- no dependence on chunk position, workgroup placement or neighbours."""
+    full batch with a ragged last chunk.  Every copy must equal ke_ref (1e-9 Ha relative in float64; in float32 the
+    per-walker budget of common.float32_budget against the float64 oracle at the rounded walker) and all copies of a
+    walker must be BIT-identical wherever they sit in the walker chunks -- no dependence on chunk position, workgroup
+    placement or neighbours."""
     from deepsolid_amd import hamiltonian, network
     fx, cell, klist, net_kw, params = load_case(name)
     dp = {k: [{kk: torch.as_tensor(vv, dtype=dtype, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
@@ -323,11 +324,15 @@ def test_full_batch_tiled_fixture_walkers(name, dtype, B):
     net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', dtype=dtype, **net_kw)
     ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(dp, x)
     ke = ke.cpu().numpy()
-    tol = 1e-9 if dtype == torch.float64 else 3e-4
+    if dtype == torch.float64:
+        ref, tol = list(fx['ke_ref'][:nw]), [1e-9] * nw
+    else:                                                 # float32: the per-walker budget of tests/common.float32_budget
+        ref, loss = float32_budget(name, nw)
+        tol = [float32_tolerance(loss, b) for b in range(nw)]
     for b in range(nw):
         copies = ke[b::nw]
         assert (copies == copies[0]).all(), (b, np.abs(copies - copies[0]).max())
-        assert abs(copies[0] - fx['ke_ref'][b]) < tol * max(1.0, abs(fx['ke_ref'][b])), (b, copies[0], fx['ke_ref'][b])
+        assert abs(copies[0] - ref[b]) < tol[b] * max(1.0, abs(ref[b])), (b, copies[0], ref[b], tol[b])
     ewn = ew.cpu().numpy()
     assert all((ewn[b::nw] == ewn[b]).all() for b in range(nw))
 
@@ -419,9 +424,10 @@ def test_large_cells_local_energy_vs_forward_laplacian_oracle(name):
 @pytest.mark.parametrize('name', ['lih', 'bcc_li', 'diamond'])
 def test_float32_chain_vs_float64_oracle(name):
     """fp32 instantiation (BASELINE config 5 is fp32; CDNA4 has no TF32, v_mfma_f32_16x16x4_f32 is
-    exact f32).  Tolerances: log|psi| 2e-3 absolute (sums over up to 96 log-dets); local kinetic energy 10x the
-    measured float32 budget of test_float32_error_budget (7e-6 at 4 e-, 6e-6 at 24 e-, 2.7e-5 at 96 e-) relative to
-    max(1, |E_kin|): 1e-4 / 1e-4 / 3e-4."""
+    exact f32).  Tolerances: log|psi| 2e-3 absolute (sums over up to 96 log-dets); local kinetic energy per walker
+    3x what the oracle's own float32 run loses (common.float32_tolerance).  A fixed number per case does not work:
+    the four diamond walkers lose 4e-6, 4e-5, 5.8e-4 and 4e-5 in the HIP chain where the float32 oracle loses 1e-5,
+    1e-4..5e-4, 4.6e-4..6.2e-4 and 2e-5..6e-5 (GPU-box host / build host)."""
     from deepsolid_amd import hamiltonian, network
     fx, cell, klist, net_kw, params = load_case(name)
     dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v]
@@ -437,12 +443,12 @@ def test_float32_chain_vs_float64_oracle(name):
     assert np.abs(phase.cpu().numpy() - fx['phase'][:nb]).max() < 5e-3
     ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', dtype=torch.float32, **net_kw)
     ke, ew = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, x)
-    for b in range(nb):
-        # the f64 oracle evaluated at the f32-rounded walker the kernel actually saw
-        xb = x[b].cpu().double()
-        ref = complex(ofl.stages(p_cpu, xb, klist, cell, net_kw)['ke'])
-        ke_tol = 3e-4 if name == 'diamond' else 1e-4
-        assert abs(complex(ke[b].cpu()) - ref) < ke_tol * max(1.0, abs(ref)), (complex(ke[b].cpu()), ref)
+    nk = len(fx['ke_ref']) if name == 'diamond' else nb   # every reference-executed walker of the 96-electron case
+    if nk > nb:
+        ke, _ = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, torch.as_tensor(fx['x'][:nk], dtype=torch.float32, device='cuda'))
+    ref, loss = float32_budget(name, nk)                  # the f64 oracle at the f32-rounded walker the kernel actually saw
+    for b in range(nk):
+        assert abs(complex(ke[b].cpu()) - ref[b]) < float32_tolerance(loss, b) * max(1.0, abs(ref[b])), (b, complex(ke[b].cpu()), ref[b], loss)
     assert np.abs(ew.cpu().numpy() - fx['ewald'][:nb].sum(-1)).max() < 2e-3 * max(1.0, np.abs(fx['ewald'][:nb].sum(-1)).max())
 
 
@@ -450,31 +456,28 @@ def test_float32_chain_vs_float64_oracle(name):
 def test_float32_error_budget(name):
     """fp32 (BASELINE config 5) error budget: what a straight float32 evaluation of the REFERENCE algorithm loses (the
     oracle's autodiff `hessian` mode and its forward-Laplacian mode run in float32 on the CPU) next to what the HIP float32
-    chain loses, both against the float64 value at the float32-rounded walker.  The HIP chain must not be worse than 3x the
-    worse of the two float32 restatements (+1e-6 relative floor); the numbers are printed for the record."""
+    chain loses, both against the float64 value at the float32-rounded walker, on every reference-executed walker (4 for
+    diamond).  Per walker the HIP chain must not be worse than 3x the float32 restatement at that walker (or 3x the case's
+    mean loss where the restatement happens to land close; +1e-6 relative floor); the numbers are printed for the record."""
     from deepsolid_amd import hamiltonian, network
     fx, cell, klist, net_kw, params = load_case(name)
-    nb = 1 if name == 'diamond' else 2
+    nb = len(fx['ke_ref']) if name == 'diamond' else 2
     dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v]
           for k, v in params.items()}
     x32 = torch.as_tensor(fx['x'][:nb], dtype=torch.float32)
     ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', dtype=torch.float32, **net_kw)
     ke, _ = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, x32.cuda())
-    p64 = onet.params_to_torch(params)
     p32 = onet.params_to_torch(params, dtype=torch.float32)
-    e_hip, e_fl, e_ad = [], [], []
+    ref, e_fl = float32_budget(name, nb)
+    e_hip = [abs(complex(ke[b].cpu()) - ref[b]) / max(1.0, abs(ref[b])) for b in range(nb)]
+    with onet.working_dtype(torch.float32):               # the autodiff restatement on walker 0 only (CPU cost)
+        net32 = oracle_net(cell, klist, net_kw, 'eval_logdet')
+        e_ad = abs(complex(sum(oham.local_kinetic_energy_real_imag_hessian(net32.apply)(p32, x32[0]))) - ref[0]) / max(1.0, abs(ref[0]))
+    print(f'{name}: relative E_kin error in float32 per walker -- HIP ' + ' '.join(f'{e:.2e}' for e in e_hip) +
+          ' | forward-Laplacian restatement ' + ' '.join(f'{e:.2e}' for e in e_fl) + f' | autodiff restatement (walker 0) {e_ad:.2e}')
     for b in range(nb):
-        ref = complex(ofl.stages(p64, x32[b].double(), klist, cell, net_kw)['ke'])
-        sc = max(1.0, abs(ref))
-        e_hip.append(abs(complex(ke[b].cpu()) - ref) / sc)
-        with onet.working_dtype(torch.float32):
-            e_fl.append(abs(complex(ofl.stages(p32, x32[b], klist, cell, net_kw)['ke']) - ref) / sc)
-            if b == 0:
-                net32 = oracle_net(cell, klist, net_kw, 'eval_logdet')
-                e_ad.append(abs(complex(sum(oham.local_kinetic_energy_real_imag_hessian(net32.apply)(p32, x32[b]))) - ref) / sc)
-    print(f'{name}: relative E_kin error in float32 -- HIP {max(e_hip):.2e}, forward-Laplacian restatement {max(e_fl):.2e}, '
-          f'autodiff restatement {max(e_ad):.2e}')
-    assert max(e_hip) <= 3 * max(max(e_fl), max(e_ad)) + 1e-6, (e_hip, e_fl, e_ad)
+        bound = max(float32_tolerance(e_fl, b), 3 * e_ad + 1e-6 if b == 0 else 0.0)
+        assert e_hip[b] <= bound, (b, e_hip, e_fl, e_ad)
 
 
 @pytest.mark.parametrize('name', OPTION_CASES)
