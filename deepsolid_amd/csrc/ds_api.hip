@@ -743,7 +743,10 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
             // hidden layers: spin means over the electrons in a bandwidth-bound pass that fills the chip (a group is one
             // workgroup's worth of GEMM), then the shared term as a K = nch*Kh product on them
             hipLaunchKernelGGL((ds::k_spin_mean<T>), dim3((unsigned)((Ksh * PV + 255) / 256), (unsigned)ng), dim3(256), 0, st, S, Gin, Kh, vb.MEANS);
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 7>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
+            // one tile per 80-walker group: with 64-feature waves a 4096-walker batch is 208 waves on 1024 SIMDs, each a serial chain
+            // of Ksh/4 x 20 MFMAs (75 us at Ksh = 512).  16-feature waves in 64-feature workgroups: four times the waves on four
+            // times the CUs, a quarter of the chain each (same products in the same order: bit-identical)
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 1, 5, 7>), dim3(1, (unsigned)ng, (unsigned)(Nout / 64)), dim3(256), 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
                                (const T*)nullptr, 0, vb.MEANS, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
                                (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
         }
@@ -766,16 +769,21 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         if (Korb % 16) return fail("orbital head with K = %d: the GEMM's operand ring needs K %% 16 == 0", Korb);
         dim3 oblock; unsigned ogz;
         gemm_geom(OC, 4, &oblock, &ogz);
-        T* PHI = vb.PHI[sp]; T* Sorb = vb.SORB[sp];
+        T* Sorb = vb.SORB[sp];
         if (s->use_last)
             hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, ogz), oblock, 2 * 16 * PV * sizeof(T), st, S, Gl,
                                blk(s->i_wsh_orb[sp]), Kl, Sorb, OC, PV, (const T*)nullptr, 0);
-        hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, Gl + (size_t)i0 * S.ldk * PV,
-                           gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, PHI, (size_t)ns * OC * PV,
-                           OC, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
-        hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, PHI, (size_t)ns * OC * PV, Q, MOUT, sp,
-                           L.MOUT, L.mout_off[S.mat_ch[sp]], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr,
-                           s->use_last ? (const T*)Sorb : (const T*)nullptr);
+        // the product with the envelope x phase factor q is the GEMM's epilogue (EPI 8): no PHI buffer, no second kernel
+        ds::OrbEpi<T> oe{Q, MOUT, L.MOUT, L.mout_off[S.mat_ch[sp]], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[S.mat_ch[sp]],
+                         S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
+#define DS_VORB(NBV, BLK, GZ) hipLaunchKernelGGL((ds::k_jet_gemm<T, NBV, 5, 8>), dim3(ns, (unsigned)ng, GZ), BLK, 0, st, Gl + (size_t)i0 * S.ldk * PV, \
+                           gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr, (size_t)0, \
+                           OC, PV, s->use_last ? (const T*)Sorb : (const T*)nullptr, (const T*)nullptr, oe)
+        // 192 columns would be three 64-column waves per workgroup: 48-column waves give four balanced ones (as in the
+        // forward-Laplacian chain's orbital head): 131 -> 94 us per 4096 bcc-Li walkers
+        if (OC % 256 != 0 && OC % 192 == 0) DS_VORB(3, dim3(256), (unsigned)(OC / 192));
+        else DS_VORB(4, oblock, ogz);
+#undef DS_VORB
     }
     if (out_logabs || out_phase || vb.MINV) {
         const size_t dstride = s->ws.DETS;

@@ -60,7 +60,7 @@ template <typename T, int NB, int ST> constexpr int ring_sets() {
 // The hidden-layer / orbital / plain-product instantiations run the four-set operand ring and need K % 16 == 0 (true for
 // every K they are launched with: hidden widths are multiples of 64, pair widths 16 or 32); layer 0 and the shared term of
 // layer 0 (K = 12, 8, ...) use the plain loop.
-__host__ __device__ constexpr bool gemm_uses_ring(int epi) { return epi == 0 || epi == 2 || epi == 4 || epi == 5; }
+__host__ __device__ constexpr bool gemm_uses_ring(int epi) { return epi == 0 || epi == 2 || epi == 4 || epi == 5 || epi == 8; }
 
 // One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x up to 1024/NB
 // output features (grid.z walks further column blocks); every wave owns 16*NB features.  Tiles 0..n_tiles-1 use (X, W, K);
@@ -74,6 +74,7 @@ __host__ __device__ constexpr bool gemm_uses_ring(int epi) { return epi == 0 || 
 //   EPI = 3/4: value chain (slots = walkers): plain tanh(Z + S + b) without / with residual.
 //   EPI = 5: orbital head (network.py:543-557): complex phi from packed columns, M = phi * q (envelope x Bloch
 //            phase 5-jet of the tile's electron) with the product rule, stored into MOUT.
+//   EPI = 8: the same for the value chain (slots = walkers): M = phi * q, values only.
 template <typename T, int NB, int ST, int EPI>
 // (very wide slot ranges, ST > 10: four waves per workgroup so that a wave may use the whole register file)
 __global__ void __launch_bounds__((NB == 3 || ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1))
@@ -282,6 +283,30 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                         __builtin_nontemporal_store(vr, &mo[s * tstride]);          // MOUT is read again only by the determinant kernels
                         __builtin_nontemporal_store(vi, &mo[s * tstride + 16]);
                     }
+                }
+            }
+    } else if (EPI == 8) {
+        // value chain (slot tiles = 80 walkers of group w): M = (phi + S + bias) * q straight from the accumulators into MOUT
+        // [group][spin][det][elec][orb][re,im][PV] -- the arithmetic of k_orbital_epilogue_val without the trip through PHI
+        const int i = oe.i0 + tile;
+        T* Mw = oe.MOUT + (size_t)w * oe.mout_stride + oe.mout_off;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int ab = 0; ab < 2; ++ab) {
+                const int p = 8 * (n0 / 16 + a) + lq + 4 * ab;
+                if (p >= oe.nparam) continue;
+                const T* q = oe.Q + ((size_t)(w * oe.N + i) * oe.nparam_max + p) * 2 * P + lr;
+                T* mo = Mw + (((size_t)((p / oe.norb) * oe.n + oe.row0 + tile) * oe.n + p % oe.norb) * 2) * P + lr;
+                const int cr = n0 + 16 * a + acc_row<T>(lane, 2 * ab), ci = n0 + 16 * a + acc_row<T>(lane, 2 * ab + 1);
+#pragma unroll
+                for (int s = 0; s < ST; ++s) {
+                    Cx<T> phi(acc[a][s][2 * ab], acc[a][s][2 * ab + 1]);
+                    if (Sb) { phi.re += Sb[((size_t)w * Nout + cr) * P + 16 * s + lr]; phi.im += Sb[((size_t)w * Nout + ci) * P + 16 * s + lr]; }
+                    if (oe.bias) { phi.re += oe.bias[p]; phi.im += oe.bias[oe.nparam + p]; }
+                    const Cx<T> v = phi * Cx<T>(q[16 * s], q[P + 16 * s]);
+                    mo[16 * s] = v.re;
+                    mo[P + 16 * s] = v.im;
                 }
             }
     } else if (EPI == 2 && DS_EXP(oe.dbg & 1)) {
