@@ -773,7 +773,17 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         if (s->use_last)
             hipLaunchKernelGGL((ds::k_shared_term<T, 4, 5>), dim3(1, (unsigned)ng, ogz), oblock, 2 * 16 * PV * sizeof(T), st, S, Gl,
                                blk(s->i_wsh_orb[sp]), Kl, Sorb, OC, PV, (const T*)nullptr, 0);
-        // the product with the envelope x phase factor q is the GEMM's epilogue (EPI 8): no PHI buffer, no second kernel
+        if (vb.MINV) {
+            // gradient pass: the raw products PHI are kept (k_orbital_bwd reads them), the product with q is its own kernel
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, Gl + (size_t)i0 * S.ldk * PV,
+                               gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, vb.PHI[sp], (size_t)ns * OC * PV,
+                               OC, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+            hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, vb.PHI[sp], (size_t)ns * OC * PV, Q, MOUT, sp,
+                               L.MOUT, L.mout_off[S.mat_ch[sp]], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr,
+                               s->use_last ? (const T*)Sorb : (const T*)nullptr);
+            continue;
+        }
+        // log psi only: the product with the envelope x phase factor q is the GEMM's epilogue (EPI 8): no PHI buffer, no second kernel
         ds::OrbEpi<T> oe{Q, MOUT, L.MOUT, L.mout_off[S.mat_ch[sp]], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[S.mat_ch[sp]],
                          S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
 #define DS_VORB(NBV, BLK, GZ) hipLaunchKernelGGL((ds::k_jet_gemm<T, NBV, 5, 8>), dim3(ns, (unsigned)ng, GZ), BLK, 0, st, Gl + (size_t)i0 * S.ldk * PV, \
