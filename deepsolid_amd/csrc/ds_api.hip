@@ -75,6 +75,7 @@ struct ds_system {
     // optional two-way chunk pipelining (DS_STREAMS=2): bandwidth-bound kernels of one chunk overlap the MFMA-bound
     // kernels of the other; the side streams fork from / join the caller's stream with events
     int n_streams = 1;
+    bool no_lu_wave = false;          // DS_NO_LU_WAVE: log det of 16 < n <= 64 by the Gauss-Jordan inverse kernel (as before round 3)
     bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
@@ -807,6 +808,14 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
 #undef DS_LU
                 continue;
             }
+            if (!vb.MINV && n <= (sizeof(T) == 4 ? 64 : 48) && !s->no_lu_wave) {      // log det only, one lane per row (float64: 48 x 2 x 2 VGPRs per row)
+                const dim3 wgrid(S.K, (unsigned)Bc);
+#define DS_LUW(NCV) hipLaunchKernelGGL((ds::k_det_lu_wave<T, NCV>), wgrid, dim3(64), 0, st, S, MOUT, L.MOUT, L.mout_off[sp], sp, (long)Bc, DETS, dstride, \
+                                       s->ws.dets_off[sp])
+                if (n <= 24) DS_LUW(24); else if (n <= 32) DS_LUW(32); else if (n <= 48) DS_LUW(48); else DS_LUW((sizeof(T) == 4 ? 64 : 48));
+#undef DS_LUW
+                continue;
+            }
             size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
             hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, MOUT, L.MOUT, L.mout_off[sp], sp,
                                vb.MINV, L.MOUT, L.mout_off[sp], DETS, dstride, s->ws.dets_off[sp], PV, PV, PV, PV);
@@ -1363,6 +1372,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     s->det_valu = getenv("DS_DET_VALU") != nullptr;
     s->det_half_slots = getenv("DS_DET_HALF_SLOTS") != nullptr;
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
+    s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     if (const char* e = getenv("DS_LAYER_GROUPS")) s->layer_groups = atoi(e) != 0;
     if (const char* e = getenv("DS_LG_PAD_LDS")) s->lg_pad_lds = (size_t)atol(e);
     if (const char* e = getenv("DS_LG_DBG")) s->lg_dbg = atoi(e);

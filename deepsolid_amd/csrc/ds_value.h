@@ -10,6 +10,7 @@
 // last walker; its results are never copied out).
 #pragma once
 #include "ds_gemm.h"
+#include <utility>
 
 namespace ds {
 
@@ -255,6 +256,91 @@ __global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __rest
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
         dw[0] = logabs;
         dw[1] = ds_atan2(ph.im, ph.re);
+    }
+}
+
+// The same for 16 < n <= NC <= 64: ONE LANE PER ROW -- a wave factorises one matrix, lane r keeps row r (NC complex values) in
+// registers.  Step k: every unused lane offers |a[r][k]|^2, a wave arg-max picks the pivot row (ties to the lower row; implicit
+// pivoting, no exchanges: the sign comes from the unused rows skipped), its lane broadcasts a[p][k..] through v_readlane -- the
+// pivot row sits in SCALAR registers for the update --, every other unused lane reduces its row.  n^3 / 3 complex multiply-adds
+// against the 2 n^3 of the Gauss-Jordan inverse on [M | 1] (k_det_inverse, one wave per matrix, LDS, a barrier pair per step)
+// that a log-psi forward used to run for these sizes although it needs no inverse: 4.48 -> 0.x ms per launch at 48 x 48 (diamond).
+// Rows / columns n .. NC-1 do not exist (lanes >= n are marked used from the start; the loop stops at n).
+// grid (K, B), block 64.
+template <typename T> __device__ __forceinline__ T wave_bcast(T x, int src);
+template <> __device__ __forceinline__ float wave_bcast<float>(float x, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+}
+template <> __device__ __forceinline__ double wave_bcast<double>(double x, int src) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// (the elimination steps are a function template over K, expanded with an integer sequence: a `for k` loop of NC steps x NC
+//  columns is past the unroller's size limit, stays a loop, and the row array -- then indexed dynamically -- lands in scratch)
+template <typename T, int NC> struct LuState {
+    unsigned long long used;
+    T logabs;
+    Cx<T> ph;
+};
+template <typename T, int NC, int K>
+__device__ __forceinline__ void lu_wave_step(Cx<T> (&a)[NC], LuState<T, NC>& st, int n, int lane) {
+    if (K >= n) return;
+    const bool free_row = !((st.used >> lane) & 1ull);
+    const T m2 = cx_abs2(a[K]);
+    T best = -1;
+    int bi = 64;
+    if (free_row && m2 > best) { best = m2; bi = lane; }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {               // wave maximum, ties to the lower row
+        const T ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    // every remaining candidate NaN: the lowest unused row becomes the pivot, log|det| comes out NaN (see k_det_lu_val)
+    if (bi >= 64) bi = __ffsll((long long)(~st.used)) - 1;
+    const int owner = __builtin_amdgcn_readfirstlane(bi);
+    if (__popcll(~st.used & ((1ull << owner) - 1ull)) & 1) st.ph = Cx<T>(-st.ph.re, -st.ph.im);
+    st.used |= 1ull << owner;
+    const Cx<T> pk(wave_bcast(a[K].re, owner), wave_bcast(a[K].im, owner));
+    const T ad = ds_sqrt(cx_abs2(pk));
+    st.logabs += ds_log(ad);
+    st.ph = st.ph * Cx<T>(pk.re / ad, pk.im / ad);
+    const Cx<T> f = a[K] * cx_inv(pk);
+    const Cx<T> nf(-f.re, -f.im);
+    const bool upd = !((st.used >> lane) & 1ull);
+#pragma unroll
+    for (int m = K + 1; m < NC; ++m) {
+        if (m < n) {
+            const Cx<T> pm(wave_bcast(a[m].re, owner), wave_bcast(a[m].im, owner));
+            const Cx<T> v = cx_fma(nf, pm, a[m]);
+            a[m].re = upd ? v.re : a[m].re;        // (component-wise: a select between two 16-byte structs is lowered through
+            a[m].im = upd ? v.im : a[m].im;        //  pointers and a memcpy, which keeps the whole row array in scratch memory)
+        }
+    }
+}
+template <typename T, int NC, int... Ks>
+__device__ __forceinline__ void lu_wave_steps(std::integer_sequence<int, Ks...>, Cx<T> (&a)[NC], LuState<T, NC>& st, int n, int lane) {
+    (lu_wave_step<T, NC, Ks>(a, st, n, lane), ...);
+}
+template <typename T, int NC>
+__global__ void __launch_bounds__(64) k_det_lu_wave(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off, int sp,
+                                                    long B, T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+    const int kdet = blockIdx.x, lane = threadIdx.x;
+    const long w = blockIdx.y;
+    const int n = S.det_n[sp];
+    const T* Mw = MOUT + (size_t)(w / PV) * mout_stride + mout_off + (size_t)kdet * n * n * 2 * PV + w % PV;
+    Cx<T> a[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        if (lane < n && m < n) a[m] = Cx<T>(Mw[(size_t)((lane * n + m) * 2) * PV], Mw[(size_t)((lane * n + m) * 2 + 1) * PV]);
+        else a[m] = Cx<T>(T(0), T(0));
+    }
+    LuState<T, NC> st{n < 64 ? (~0ull << n) : 0ull, T(0), Cx<T>(1, 0)};      // used: bit r = row r has been a pivot (or does not exist)
+    lu_wave_steps<T, NC>(std::make_integer_sequence<int, NC>(), a, st, n, lane);
+    if (lane == 0 && w < B) {
+        T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
+        dw[0] = st.logabs;
+        dw[1] = ds_atan2(st.ph.im, st.ph.re);
     }
 }
 

@@ -3,6 +3,8 @@ golden vectors executed from the reference (through the C ABI, deepsolid_amd.dev
 
 Tolerances (float64): forward quantities 1e-10 absolute/relative, local energies 1e-8 Ha
 (north star: 1e-6 Ha)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -386,6 +388,33 @@ def test_value_chain_log_det_propagates_nan():
     step = qmc.make_mcmc_step(slog.apply, 4, cell.a, steps=1)
     x1, pm = step(dp, x0, (nz, un), 0.02)
     assert torch.equal(x1[2], x0[2]) and abs(float(pm) - 0.75) < 1e-12
+
+
+@pytest.mark.parametrize('name,dtype', [('graphene', torch.float64), ('diamond', torch.float64), ('diamond', torch.float32)])
+def test_log_det_one_lane_per_row_lu(name, dtype, monkeypatch):
+    """Matrices of 24 x 24 and 48 x 48 (log psi only): the register LU with one lane per row (k_det_lu_wave) against the
+    Gauss-Jordan inverse kernel it replaces (DS_NO_LU_WAVE=1) and against the reference-executed fixture; a NaN coordinate must
+    give a NaN log|psi| for that walker only (a Metropolis move into it is then rejected), as with the other determinant kernels."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=dtype, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    nb = len(fx['logabs'])
+    x = torch.as_tensor(fx['x'][:nb], dtype=dtype, device='cuda')
+    monkeypatch.setenv('DS_NO_LU_WAVE', '1')
+    la_gj, ph_gj = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), dtype).logpsi(dp, x)
+    monkeypatch.delenv('DS_NO_LU_WAVE')
+    sd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), dtype)
+    la, ph = sd.logpsi(dp, x)
+    f64 = dtype == torch.float64
+    assert (la - la_gj).abs().max().item() < (1e-10 if f64 else 2e-2)
+    d = (ph - ph_gj + math.pi) % (2 * math.pi) - math.pi if ph.dim() == 1 else ph - ph_gj
+    assert d.abs().max().item() < (1e-10 if f64 else 2e-2)
+    np.testing.assert_allclose(la.cpu().numpy(), fx['logabs'][:nb], atol=1e-9 if f64 else 2e-3)
+    xn = x.clone()
+    xn[1, 4] = float('nan')
+    la_n, _ = sd.logpsi(dp, xn)
+    assert torch.isnan(la_n[1]) and torch.isfinite(la_n[0]) and (nb < 3 or torch.isfinite(la_n[2:]).all())
 
 
 @pytest.mark.parametrize('name', ['graphene', 'diamond'])

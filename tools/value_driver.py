@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Workload for profiling the value chain: 5 log-psi evaluations of 4096 bcc-Li walkers."""
+"""Workload for profiling the value chain: 5 log-psi evaluations (default 4096 bcc-Li walkers, float64).
+    python tools/value_driver.py [system] [batch] [f64|f32]"""
 import os
 import sys
 
@@ -8,10 +9,13 @@ import torch
 
 from deepsolid_amd import network, systems
 
-cell, klist = systems.build('bcc_li')
-net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', **systems.DETNET_DEFAULTS)
+name = sys.argv[1] if len(sys.argv) > 1 else 'bcc_li'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+dtype = torch.float32 if len(sys.argv) > 3 and sys.argv[3] == 'f32' else torch.float64
+cell, klist = systems.build(name)
+net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_slogdet', dtype=dtype, **systems.DETNET_DEFAULTS)
 params = net.init(0)
-x = torch.as_tensor(systems.synthetic_walkers(cell, 4096), device='cuda')
+x = torch.as_tensor(systems.synthetic_walkers(cell, B), dtype=dtype, device='cuda')
 for _ in range(5):
     lp = net.apply(params, x)
 torch.cuda.synchronize()
