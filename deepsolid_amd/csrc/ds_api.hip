@@ -699,9 +699,12 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
     const int64_t ng = (Bc + PV - 1) / PV;
     T* ZB = vb.ZB; T* Q = vb.Q; T* MOUT = vb.MOUT; T* DETS = vb.DETS;
     auto blk = [&](int i) { return params + s->blocks[i].offset; };
-    hipLaunchKernelGGL((ds::k_features_val<T, 0>), dim3((unsigned)ng, ds::FV_SPLIT), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
+    // workgroups per 80-walker group: at least FV_SPLIT, and enough for ~2048 workgroups in all (13 groups of diamond walkers
+    // x 16 were 208 workgroups looping 180 times each)
+    const unsigned fsplit = (unsigned)std::min<int64_t>(256, std::max<int64_t>(ds::FV_SPLIT, (2048 + ng - 1) / ng));
+    hipLaunchKernelGGL((ds::k_features_val<T, 0>), dim3((unsigned)ng, fsplit), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
                        blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), vb.Gl[0], vb.MEAN0, vb.H2l[0], Q);
-    hipLaunchKernelGGL((ds::k_features_val<T, 1>), dim3((unsigned)ng, ds::FV_SPLIT), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
+    hipLaunchKernelGGL((ds::k_features_val<T, 1>), dim3((unsigned)ng, fsplit), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
                        blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), vb.Gl[0], vb.MEAN0, vb.H2l[0], Q);
     const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
     const bool fuse_means = S.n_up >= 8 && (S.n_dn >= 8 || S.n_dn == 0) && !s->no_fuse_means;
