@@ -278,11 +278,17 @@ template <> __device__ __forceinline__ double wave_bcast<double>(double x, int s
 }
 // (the elimination steps are a function template over K, expanded with an integer sequence: a `for k` loop of NC steps x NC
 //  columns is past the unroller's size limit, stays a loop, and the row array -- then indexed dynamically -- lands in scratch)
+// det = (product of the pivots, kept as a complex number rescaled by its binary exponent at every step) * 2^esum: one log and
+// one atan2 per matrix instead of a log, a square root and two divisions per pivot
 template <typename T, int NC> struct LuState {
     unsigned long long used;
-    T logabs;
+    int esum;
     Cx<T> ph;
 };
+__device__ __forceinline__ int ds_frexp_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }
+__device__ __forceinline__ int ds_frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
+__device__ __forceinline__ float ds_ldexp(float x, int e) { return ldexpf(x, e); }
+__device__ __forceinline__ double ds_ldexp(double x, int e) { return ldexp(x, e); }
 template <typename T, int NC, int K>
 __device__ __forceinline__ void lu_wave_step(Cx<T> (&a)[NC], LuState<T, NC>& st, int n, int lane) {
     if (K >= n) return;
@@ -302,9 +308,13 @@ __device__ __forceinline__ void lu_wave_step(Cx<T> (&a)[NC], LuState<T, NC>& st,
     if (__popcll(~st.used & ((1ull << owner) - 1ull)) & 1) st.ph = Cx<T>(-st.ph.re, -st.ph.im);
     st.used |= 1ull << owner;
     const Cx<T> pk(wave_bcast(a[K].re, owner), wave_bcast(a[K].im, owner));
-    const T ad = ds_sqrt(cx_abs2(pk));
-    st.logabs += ds_log(ad);
-    st.ph = st.ph * Cx<T>(pk.re / ad, pk.im / ad);
+    st.ph = st.ph * pk;
+    {
+        const T big = ds_abs(st.ph.re) > ds_abs(st.ph.im) ? ds_abs(st.ph.re) : ds_abs(st.ph.im);      // (NaN: the exponent is ignored, NaN stays)
+        const int e = big > T(0) ? ds_frexp_exp(big) : 0;
+        st.ph = Cx<T>(ds_ldexp(st.ph.re, -e), ds_ldexp(st.ph.im, -e));
+        st.esum += e;
+    }
     const Cx<T> f = a[K] * cx_inv(pk);
     const Cx<T> nf(-f.re, -f.im);
     const bool upd = !((st.used >> lane) & 1ull);
@@ -335,11 +345,11 @@ __global__ void __launch_bounds__(64) k_det_lu_wave(SysDev<T> S, const T* __rest
         if (lane < n && m < n) a[m] = Cx<T>(Mw[(size_t)((lane * n + m) * 2) * PV], Mw[(size_t)((lane * n + m) * 2 + 1) * PV]);
         else a[m] = Cx<T>(T(0), T(0));
     }
-    LuState<T, NC> st{n < 64 ? (~0ull << n) : 0ull, T(0), Cx<T>(1, 0)};      // used: bit r = row r has been a pivot (or does not exist)
+    LuState<T, NC> st{n < 64 ? (~0ull << n) : 0ull, 0, Cx<T>(1, 0)};      // used: bit r = row r has been a pivot (or does not exist)
     lu_wave_steps<T, NC>(std::make_integer_sequence<int, NC>(), a, st, n, lane);
     if (lane == 0 && w < B) {
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
-        dw[0] = st.logabs;
+        dw[0] = T(0.5) * ds_log(cx_abs2(st.ph)) + T(st.esum) * T(0.69314718055994530942);
         dw[1] = ds_atan2(st.ph.im, st.ph.re);
     }
 }
