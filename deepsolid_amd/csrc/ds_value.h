@@ -294,16 +294,24 @@ __device__ __forceinline__ void lu_wave_step(Cx<T> (&a)[NC], LuState<T, NC>& st,
     if (K >= n) return;
     const bool free_row = !((st.used >> lane) & 1ull);
     const T m2 = cx_abs2(a[K]);
-    T best = -1;
-    int bi = 64;
-    if (free_row && m2 > best) { best = m2; bi = lane; }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {               // wave maximum, ties to the lower row
-        const T ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    // pivot = the unused row with the largest |a[r][K]|^2, the lowest such row on a tie: maximum over each 16-lane row on DPP,
+    // over the four rows through v_readlane, then a ballot of the lanes that hold it (the butterfly of ds_bpermute shuffles
+    // this replaces cost 18 trips through the LDS crossbar per step in float64)
+    T best = free_row ? m2 : T(-1);
+    best = best > T(-1) ? best : T(-1);                            // NaN candidates do not take part
+    {
+        T o;
+        o = dpp_mov<0xB1>(best);  best = o > best ? o : best;
+        o = dpp_mov<0x4E>(best);  best = o > best ? o : best;
+        o = dpp_mov<0x141>(best); best = o > best ? o : best;
+        o = dpp_mov<0x140>(best); best = o > best ? o : best;
+        const T r0 = wave_bcast(best, 0), r1 = wave_bcast(best, 16), r2 = wave_bcast(best, 32), r3 = wave_bcast(best, 48);
+        const T m01 = r1 > r0 ? r1 : r0, m23 = r3 > r2 ? r3 : r2;
+        best = m23 > m01 ? m23 : m01;
     }
-    // every remaining candidate NaN: the lowest unused row becomes the pivot, log|det| comes out NaN (see k_det_lu_val)
-    if (bi >= 64) bi = __ffsll((long long)(~st.used)) - 1;
+    const unsigned long long hit = __ballot(free_row && m2 == best);
+    // every remaining candidate NaN (nobody holds the maximum -1): the lowest unused row becomes the pivot, log|det| comes out NaN
+    int bi = hit ? __ffsll((long long)hit) - 1 : __ffsll((long long)(~st.used)) - 1;
     const int owner = __builtin_amdgcn_readfirstlane(bi);
     if (__popcll(~st.used & ((1ull << owner) - 1ull)) & 1) st.ph = Cx<T>(-st.ph.re, -st.ph.im);
     st.used |= 1ull << owner;
