@@ -277,13 +277,19 @@ __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __re
     const int lr = lane & 15, lq = lane >> 4;
     const T* Hw = Hin + (size_t)w * Kin * 5 * NP + pt * 16 + lr;
     acc_t acc[NT2][5];
+#pragma unroll
     for (int a = 0; a < NT2; ++a)
+#pragma unroll
         for (int c = 0; c < 5; ++c) acc[a][c] = acc_t{0, 0, 0, 0};
     for (int ks = 0; ks < Kin / 4; ++ks) {
         T av[NT2], bv[5];
+#pragma unroll
         for (int a = 0; a < NT2; ++a) av[a] = W[(size_t)(4 * ks + lq) * Kout + 16 * a + lr];
+#pragma unroll
         for (int c = 0; c < 5; ++c) bv[c] = Hw[(size_t)((4 * ks + lq) * 5 + c) * NP];
+#pragma unroll
         for (int a = 0; a < NT2; ++a)
+#pragma unroll
             for (int c = 0; c < 5; ++c) acc[a][c] = mfma16(av[a], bv[c], acc[a][c]);
     }
     const T rs2 = T(0.70710678118654752440);
@@ -300,7 +306,9 @@ __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __re
         pm_slot = sg - seg_of(pt * 16);
         pm_last = pm_valid && (lr == 15 || seg_of(p + 1) != sg);
     }
+#pragma unroll
     for (int a = 0; a < NT2; ++a)
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = 16 * a + acc_row<T>(lane, r);
             const T z0 = acc[a][0][r] + bias[n];
@@ -310,6 +318,7 @@ __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __re
             if (VAL) {   // value chain: the five columns are five independent walkers
                 o[1] = ds_tanh(z1 + bias[n]); o[2] = ds_tanh(z2 + bias[n]); o[3] = ds_tanh(z3 + bias[n]); o[4] = ds_tanh(z4 + bias[n]);
             }
+#pragma unroll
             for (int c = 0; c < 5; ++c) {
                 T v = o[c];
                 if (RES) v = (Hw[(size_t)(n * 5 + c) * NP] + v) * rs2;
