@@ -615,6 +615,9 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const bool sw8 = ybytes16 > 160 * 1024;
         const size_t ybytes = sw8 ? ybytes8 : ybytes16;
         if ((2 * n) % 4 == 0 && ybytes <= 160 * 1024 && nt <= 6 && !s->det_valu) {
+#define DS_TRMF(NTV, SWV, NWV, NF) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV, NF>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
+                                            L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
+                                            L.dets_off[sp])
 #define DS_TRM(NTV, SWV, NWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp])
@@ -625,13 +628,16 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 constexpr int NWS = 4;
                 const size_t sbytes = (size_t)(n / 2) * 2 * n * 16 * sizeof(T) + 512 * sizeof(ds::Cx<T>);
 #define DS_TRS(NTV) hipLaunchKernelGGL((ds::k_det_trace_mfma_split<T, NTV, NWS, (NTV <= 4 || sizeof(T) == 4 ? 2 : 1)>), dim3(S.K, (unsigned)Bc), dim3(64 * NWS), sbytes, st, S, c.MOUT, L.MOUT,  \
-                                       L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS, L.dets_off[sp])
+                                       L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS, L.dets_off[sp], \
+                                       (s->lg_dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr)
                 if (n == 32) DS_TRS(4); else DS_TRS(6);        // 2n = 16 NT exactly
 #undef DS_TRS
             } else if (sw8) { if (nt <= 4) DS_TRM(4, 8, 4); else DS_TRM(6, 8, 4); }
+            else if (n == 12) DS_TRMF(2, 16, 4, 12); else if (n == 24) DS_TRMF(3, 16, 8, 24);      // (compile-time n: see the kernel)
             else if (nt == 1) DS_TRM(1, 16, 4); else if (nt == 2) DS_TRM(2, 16, 4); else if (nt == 3) DS_TRM(3, 16, 8); else if (nt == 4) DS_TRM(4, 16, 8);
             else DS_TRM(6, 16, 4);
 #undef DS_TRM
+#undef DS_TRMF
         } else
         if (n <= 16) DS_TRACE(16, 16);
         else if (n <= 32) DS_TRACE(32, 8);

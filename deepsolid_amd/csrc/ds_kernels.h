@@ -555,7 +555,10 @@ __global__ void __launch_bounds__(256) k_det_trace(SysDev<T> S, const T* __restr
 // SW = slots of a 16-slot MFMA tile parked in LDS per pass: 16, or 8 (two passes over the tile, the products are
 // recomputed) when n * 2n * 16 elements do not fit the LDS.
 // NW = waves per workgroup: 8 for the matrices whose Y tile leaves room for one workgroup per CU only (two waves per SIMD).
-template <typename T, int NT, int SW, int NW = 4>
+// NFIX = the matrix size when it is known at compile time (12 and 24: the 24- and 48-electron cells of the benchmark configurations),
+// 0 = read from the descriptor: with a constant n the index arithmetic of the pair sums (a division and a remainder per term) and
+// the LDS addresses fold into constants.
+template <typename T, int NT, int SW, int NW = 4, int NFIX = 0>
 __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                         int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                         T* __restrict__ TR, size_t tr_stride, size_t tr_off,
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lq = lane >> 4;
-    const int P = S.P, n = S.det_n[ch], n2 = 2 * n, nks = n2 / 4;
+    const int P = S.P, n = NFIX ? NFIX : S.det_n[ch], n2 = 2 * n, nks = n2 / 4;
     T* Y = reinterpret_cast<T*>(smem_raw);               // [n][2n][SW]
     Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)n * n2 * SW);   // [NTHR]
     const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
@@ -639,6 +642,7 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
         // n-1-r together hold n+1 entries (n even); odd n walks the full square.
         const bool tri = (n & 1) == 0;
         const int npair = tri ? (n / 2) * (n + 1) : n * n;
+#pragma unroll 4
         for (int pi = g; pi < npair; pi += NG) {
             int i, e;
             if (tri) {
@@ -687,13 +691,23 @@ template <typename T, int NT, int NW = 4, int PF = 2>
 __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                               int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                               T* __restrict__ TR, size_t tr_stride, size_t tr_off,
-                                                              T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+                                                              T* __restrict__ DETS, size_t dets_stride, size_t dets_off,
+                                                              unsigned long long* __restrict__ tl = nullptr) {
+    // tl (kernel development): workgroup (0, 0) writes per-wave cycle totals of its phases -- [wave][0..7] = fragment setup, products,
+    // wait at the barrier after them, pair sums, wait after them, per-tile trace reduction, whole kernel, 0
     typedef typename Acc4<T>::type acc_t;
     constexpr int KSMAX = 4 * NT, NTHR = 64 * NW, NG = NTHR / 16;
+    const bool stamp = tl && blockIdx.x == 0 && blockIdx.y == 0;
+    long long c_setup = 0, c_prod = 0, c_bar1 = 0, c_pairs = 0, c_bar2 = 0, c_red = 0, c_t = 0;
+    const long long c_begin = stamp ? clock64() : 0;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lq = lane >> 4;
-    const int P = S.P, n = S.det_n[ch], n2 = 2 * n, nks = n2 / 4, h = n / 2, nth = n / 16;      // nth: accumulator tiles per column half
+    // n = 8 NT exactly (the launcher's condition for this kernel): compile-time, so that the index arithmetic of the pair sums
+    // (a division and a remainder by h or h + 1 per term) and every LDS address fold into constants -- with n read from the
+    // descriptor the pair sums cost 320 cycles per term and 18 % of the kernel
+    constexpr int n = 8 * NT, n2 = 2 * n, nks = n2 / 4, h = n / 2;
+    const int P = S.P;
     T* Y = reinterpret_cast<T*>(smem_raw);               // [h][2n][16]
     Cx<T>* red = reinterpret_cast<Cx<T>*>(Y + (size_t)h * n2 * 16);   // [NTHR]
     const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
@@ -713,6 +727,7 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, c
             }
             af[nt][ks] = v;
         }
+    if (stamp) c_setup = clock64() - c_begin;
     Cx<T> y2(0, 0);
     const int d = tid & 15, g = tid >> 4;
     // The wave's rows over all slot tiles and passes form one sequence q = ((tile, pass), row): the operands of row q + PF are
@@ -759,12 +774,17 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, c
                 }
             };
             // (the launcher guarantees 2 * nth == NT: n = 8 NT)
+            if (stamp) c_t = clock64();
             if (pass == 0) products(std::integral_constant<int, 0>(), std::integral_constant<int, NT>());
             else if (pass == 1) products(std::integral_constant<int, 0>(), std::integral_constant<int, NT / 2>());
             else products(std::integral_constant<int, NT / 2>(), std::integral_constant<int, NT>());
+            if (stamp) { const long long c = clock64(); c_prod += c - c_t; c_t = c; }
             __syncthreads();
+            if (stamp) { const long long c = clock64(); c_bar1 += c - c_t; c_t = c; }
             // pairs of this pass.  Y row index = electron - (h if the electron is in I2); the column keeps its global index
             if (pass == 1) {          // i in I1 (rows still from pass A, columns C2), e in I2 (rows from pass B, columns C1): weight 2
+                // (unrolled: with one wave per SIMD a term is otherwise as long as the latency of its four LDS reads)
+#pragma unroll 6
                 for (int pi = g; pi < h * h && slot >= 2; pi += NG) {
                     const int i = pi / h, e = h + pi % h;
                     const Cx<T> yie(Y[((size_t)i * n2 + 2 * e) * 16 + d], Y[((size_t)i * n2 + 2 * e + 1) * 16 + d]);
@@ -774,6 +794,7 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, c
             } else {                  // upper triangle of the diagonal block (electrons off .. off + h - 1)
                 const int off = pass == 0 ? 0 : h;
                 // rows r and h-1-r of the triangle hold h+1 entries together: a rectangle (h/2) x (h+1), no search
+#pragma unroll 6
                 for (int pi = g; pi < (h / 2) * (h + 1); pi += NG) {
                     const int rr = pi / (h + 1), tt = pi - rr * (h + 1);
                     const int r = tt < h - rr ? rr : h - 1 - rr, t = tt < h - rr ? tt : tt - (h - rr);
@@ -786,7 +807,9 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, c
                     }
                 }
             }
+            if (stamp) { const long long c = clock64(); c_pairs += c - c_t; c_t = c; }
             __syncthreads();
+            if (stamp) { const long long c = clock64(); c_bar2 += c - c_t; c_t = c; }
         }
         red[tid] = trc;
         __syncthreads();
@@ -797,6 +820,11 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, c
             Tw[P + slot] = t.im;
         }
         __syncthreads();
+        if (stamp) { const long long c = clock64(); c_red += c - c_t; c_t = c; }
+    }
+    if (stamp && lane == 0) {
+        unsigned long long* o = tl + wave * 8;
+        o[0] = c_setup; o[1] = c_prod; o[2] = c_bar1; o[3] = c_pairs; o[4] = c_bar2; o[5] = c_red; o[6] = clock64() - c_begin; o[7] = 0;
     }
     red[tid] = y2;
     __syncthreads();
