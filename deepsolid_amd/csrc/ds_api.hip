@@ -617,7 +617,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         if ((2 * n) % 4 == 0 && ybytes <= 160 * 1024 && nt <= 6 && !s->det_valu) {
 #define DS_TRMF(NTV, SWV, NWV, NF) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV, NF>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
-                                            L.dets_off[sp])
+                                            L.dets_off[sp], (s->lg_dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr)
 #define DS_TRM(NTV, SWV, NWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp])

@@ -562,8 +562,13 @@ template <typename T, int NT, int SW, int NW = 4, int NFIX = 0>
 __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
                                                         int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
                                                         T* __restrict__ TR, size_t tr_stride, size_t tr_off,
-                                                        T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+                                                        T* __restrict__ DETS, size_t dets_stride, size_t dets_off,
+                                                        unsigned long long* __restrict__ tl = nullptr) {
     typedef typename Acc4<T>::type acc_t;
+    // tl (kernel development): per-wave cycle totals of workgroup (0, 0), as in k_det_trace_mfma_split
+    const bool stamp = tl && blockIdx.x == 0 && blockIdx.y == 0;
+    long long c_setup = 0, c_prod = 0, c_bar1 = 0, c_pairs = 0, c_bar2 = 0, c_red = 0, c_t = 0;
+    const long long c_begin = stamp ? clock64() : 0;
     constexpr int KSMAX = 4 * NT;                         // 2n <= 16 NT  ->  2n / 4 <= 4 NT k-steps
     constexpr int NTHR = 64 * NW, NG = NTHR / SW;         // NG thread groups in the trace phase
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -596,6 +601,25 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
     // the MFMAs of row q, across the tile boundaries too, so the trace phase of a tile hides the latency of the next tile's
     // first rows (large matrices run one workgroup per CU: nothing else would).
     const int nsp = (P / 16) * (16 / SW), R = wave < n ? (n - wave + NW - 1) / NW : 0, total = R * nsp;
+    // Known matrix size with the same number of rows for every wave (n = 12 on 4 waves, 24 on 8: three rows each): ALL rows of
+    // the next slot tile are requested before the products of the current one -- a whole tile (products, pair sums, two barriers)
+    // of latency cover.  With the rows requested two ahead, three rows of 12 MFMAs per tile left the products phase waiting for
+    // memory: 11 k cycles per tile for 2.3 k cycles of MFMAs (tools/trace_timeline.py).
+    // (only while the two operand tiles stay within ~96 VGPRs: at n = 24 in float64 they take 144 next to 72 of A fragments, the
+    //  kernel spills and the products phase becomes 2.5 times slower)
+    constexpr bool TILE_PF = NFIX > 0 && NFIX % NW == 0 && SW == 16 && 2 * (NFIX / NW) * KSMAX * ((int)sizeof(T) / 4) <= 96;
+    constexpr int RW = TILE_PF ? NFIX / NW : 1;
+    T cur[RW][KSMAX], nxt[RW][KSMAX];
+    auto load_tile = [&](T (&b)[RW][KSMAX], int st) {
+        if (st < nsp) {
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr) {
+                const T* xp = Mw + ((size_t)st * n * n2 + (size_t)(wave + NW * rr) * n2 + lq) * 16 + lr;
+#pragma unroll
+                for (int ks = 0; ks < KSMAX; ++ks) b[rr][ks] = ks < nks ? xp[(size_t)(4 * ks) * 16] : T(0);
+            }
+        }
+    };
     T bc[KSMAX], bn[KSMAX], bm[KSMAX];
     auto load_q = [&](T (&b)[KSMAX], int q) {
         if (q < total) {
@@ -605,11 +629,41 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
             for (int ks = 0; ks < KSMAX; ++ks) b[ks] = ks < nks ? xp[(size_t)(4 * ks) * 16] : T(0);
         }
     };
-    load_q(bc, 0);
-    load_q(bn, 1);
+    if (TILE_PF) load_tile(cur, 0);
+    else { load_q(bc, 0); load_q(bn, 1); }
     int q = 0;
+    if (stamp) c_setup = clock64() - c_begin;
     for (int sp = 0; sp < nsp; ++sp) {
         const int st = sp / (16 / SW), half = sp % (16 / SW);
+        if (stamp) c_t = clock64();
+        if (TILE_PF) {
+            load_tile(nxt, sp + 1);
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr) {
+                const int i = wave + NW * rr;
+                acc_t acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = acc_t{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KSMAX; ++ks) {
+                    if (ks < nks) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(af[nt][ks], cur[rr][ks], acc[nt]);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int np = 16 * nt + acc_row<T>(lane, r);
+                        if (np < n2) Y[((size_t)i * n2 + np) * SW + lr] = acc[nt][r];
+                    }
+            }
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                for (int ks = 0; ks < KSMAX; ++ks) cur[rr][ks] = nxt[rr][ks];
+        } else
         for (int i = wave; i < n; i += NW, ++q) {
             load_q(bm, q + 2);
             acc_t acc[NT];
@@ -634,7 +688,9 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
                     }
             }
         }
+        if (stamp) { const long long c = clock64(); c_prod += c - c_t; c_t = c; }
         __syncthreads();
+        if (stamp) { const long long c = clock64(); c_bar1 += c - c_t; c_t = c; }
         const int slot = 16 * st + SW * half + d;
         const bool live = slot >= 1 && slot < S.D;
         Cx<T> trc(0, 0);
@@ -657,8 +713,10 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
                 y2 = cx_fma(wgt * yie, yei, y2);
             }
         }
+        if (stamp) { const long long c = clock64(); c_pairs += c - c_t; c_t = c; }
         red[tid] = trc;
         __syncthreads();
+        if (stamp) { const long long c = clock64(); c_bar2 += c - c_t; c_t = c; }
         if (g == 0 && live) {
             Cx<T> t(0, 0);
             for (int u = 0; u < NG; ++u) t = t + red[u * SW + d];
@@ -666,6 +724,11 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
             Tw[P + slot] = t.im;
         }
         __syncthreads();
+        if (stamp) { const long long c = clock64(); c_red += c - c_t; c_t = c; }
+    }
+    if (stamp && lane == 0) {
+        unsigned long long* o = tl + wave * 8;
+        o[0] = c_setup; o[1] = c_prod; o[2] = c_bar1; o[3] = c_pairs; o[4] = c_bar2; o[5] = c_red; o[6] = clock64() - c_begin; o[7] = 0;
     }
     red[tid] = y2;
     __syncthreads();
