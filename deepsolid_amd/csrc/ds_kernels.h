@@ -659,10 +659,6 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
                         if (np < n2) Y[((size_t)i * n2 + np) * SW + lr] = acc[nt][r];
                     }
             }
-#pragma unroll
-            for (int rr = 0; rr < RW; ++rr)
-#pragma unroll
-                for (int ks = 0; ks < KSMAX; ++ks) cur[rr][ks] = nxt[rr][ks];
         } else
         for (int i = wave; i < n; i += NW, ++q) {
             load_q(bm, q + 2);
@@ -725,6 +721,12 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
         }
         __syncthreads();
         if (stamp) { const long long c = clock64(); c_red += c - c_t; c_t = c; }
+        if (TILE_PF) {      // (here, not after the products: the wait for the next tile's rows then has the whole tile as cover)
+#pragma unroll
+            for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                for (int ks = 0; ks < KSMAX; ++ks) cur[rr][ks] = nxt[rr][ks];
+        }
     }
     if (stamp && lane == 0) {
         unsigned long long* o = tl + wave * 8;
