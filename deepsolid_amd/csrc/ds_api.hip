@@ -1231,8 +1231,8 @@ int mcmc_step_impl(ds_system* s, const void* params, void* x_, void* lp_, int64_
                            normals ? normals + (size_t)i * nstride : (const T*)nullptr, key, (unsigned long long)i, (T)width, ne, X2,
                            S.N, only);
         if (int rc = logpsi_impl<T>(s, params, X2, B, LA2, nullptr, wsv, wsv_bytes, st)) return rc;
-        hipLaunchKernelGGL((ds::k_mcmc_accept<T>), dim3((unsigned)B), dim3(64), 0, st, x, lp, X2, LA2,
-                           uniforms ? uniforms + (size_t)i * B : (const T*)nullptr, key, (unsigned long long)i, 3 * S.N, 0L, (T*)n_accept);
+        hipLaunchKernelGGL((ds::k_mcmc_accept<T>), dim3((unsigned)((B + 63) / 64)), dim3(256), 0, st, x, lp, X2, LA2,
+                           uniforms ? uniforms + (size_t)i * B : (const T*)nullptr, key, (unsigned long long)i, 3 * S.N, 0L, (long)B, (T*)n_accept);
     }
     HIP_OK(hipGetLastError());
     return 0;

@@ -93,22 +93,37 @@ __global__ void k_mcmc_propose(const T* __restrict__ a, const T* __restrict__ ai
 }
 
 // lp2 = 2 log|psi(x2)|; accept iff lp2 - lp1 > log u; select x, lp; count      qmc.py:195-196, 217-222
-// one workgroup per walker; n_accept is an integer-valued count, so the order of the atomic adds does not matter
+// 64 walkers per workgroup; n_accept is an integer-valued count, so the order of the atomic adds does not matter
 template <typename T>
-__global__ void k_mcmc_accept(T* __restrict__ x1, T* __restrict__ lp1, const T* __restrict__ x2, const T* __restrict__ logabs2,
-                              const T* __restrict__ uniform, PhiloxKey key, unsigned long long step, int n3, long w0,
-                              T* __restrict__ n_accept) {
-    const long w = blockIdx.x;
-    const T lp2 = 2 * logabs2[w];
-    const T u = uniform ? uniform[w] : (T)philox_uniform(key, step, (unsigned long long)(w0 + w));
-    const bool cond = (lp2 - lp1[w]) > ds_log(u);
-    if (cond)
-        for (int c = threadIdx.x; c < n3; c += blockDim.x) x1[(size_t)w * n3 + c] = x2[(size_t)w * n3 + c];
-    __syncthreads();
-    if (threadIdx.x == 0 && cond) {
-        lp1[w] = lp2;
-        atomicAdd(n_accept, T(1));
+__global__ void __launch_bounds__(256) k_mcmc_accept(T* __restrict__ x1, T* __restrict__ lp1, const T* __restrict__ x2,
+                                                     const T* __restrict__ logabs2, const T* __restrict__ uniform, PhiloxKey key,
+                                                     unsigned long long step, int n3, long w0, long B, T* __restrict__ n_accept) {
+    // 64 walkers per workgroup: the first wave takes the 64 decisions and counts the accepted ones with a ballot -- ONE atomic
+    // per workgroup (a workgroup per walker meant ~0.9 B atomics on the same word per move: 48 us at 4096 walkers, most of this
+    // kernel) --, then the four waves copy the accepted walkers.  The count is a sum of exact small integers: order-independent.
+    __shared__ unsigned long long mask_s;
+    const long wb = (long)blockIdx.x * 64;
+    if (threadIdx.x < 64) {
+        const long w = wb + threadIdx.x;
+        bool cond = false;
+        if (w < B) {
+            const T lp2 = 2 * logabs2[w];
+            const T u = uniform ? uniform[w] : (T)philox_uniform(key, step, (unsigned long long)(w0 + w));
+            cond = (lp2 - lp1[w]) > ds_log(u);
+            if (cond) lp1[w] = lp2;
+        }
+        const unsigned long long m = __ballot(cond);
+        if (threadIdx.x == 0) {
+            mask_s = m;
+            if (m) atomicAdd(n_accept, T(__popcll(m)));
+        }
     }
+    __syncthreads();
+    const unsigned long long m = mask_s;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < 64; k += 4)
+        if ((m >> k) & 1ull)
+            for (int c = lane; c < n3; c += 64) x1[(size_t)(wb + k) * n3 + c] = x2[(size_t)(wb + k) * n3 + c];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
