@@ -846,29 +846,39 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, c
             if (stamp) { const long long c = clock64(); c_prod += c - c_t; c_t = c; }
             __syncthreads();
             if (stamp) { const long long c = clock64(); c_bar1 += c - c_t; c_t = c; }
-            // pairs of this pass.  Y row index = electron - (h if the electron is in I2); the column keeps its global index
-            if (pass == 1) {          // i in I1 (rows still from pass A, columns C2), e in I2 (rows from pass B, columns C1): weight 2
-                // (unrolled: with one wave per SIMD a term is otherwise as long as the latency of its four LDS reads)
-#pragma unroll 6
-                for (int pi = g; pi < h * h && slot >= 2; pi += NG) {
-                    const int i = pi / h, e = h + pi % h;
-                    const Cx<T> yie(Y[((size_t)i * n2 + 2 * e) * 16 + d], Y[((size_t)i * n2 + 2 * e + 1) * 16 + d]);
-                    const Cx<T> yei(Y[((size_t)(e - h) * n2 + 2 * i) * 16 + d], Y[((size_t)(e - h) * n2 + 2 * i + 1) * 16 + d]);
-                    y2 = cx_fma(T(2) * yie, yei, y2);
-                }
-            } else {                  // upper triangle of the diagonal block (electrons off .. off + h - 1)
-                const int off = pass == 0 ? 0 : h;
-                // rows r and h-1-r of the triangle hold h+1 entries together: a rectangle (h/2) x (h+1), no search
-#pragma unroll 6
-                for (int pi = g; pi < (h / 2) * (h + 1); pi += NG) {
-                    const int rr = pi / (h + 1), tt = pi - rr * (h + 1);
-                    const int r = tt < h - rr ? rr : h - 1 - rr, t = tt < h - rr ? tt : tt - (h - rr);
-                    const int i = off + r, e = off + r + t;
-                    const Cx<T> yie(Y[((size_t)r * n2 + 2 * e) * 16 + d], Y[((size_t)r * n2 + 2 * e + 1) * 16 + d]);
-                    if (i == e) trc = trc + yie;
-                    if (slot >= 2) {
-                        const Cx<T> yei(Y[((size_t)(e - off) * n2 + 2 * i) * 16 + d], Y[((size_t)(e - off) * n2 + 2 * i + 1) * 16 + d]);
-                        y2 = cx_fma((i != e ? T(2) : T(1)) * yie, yei, y2);
+            // pairs of this pass.  Y row index = electron - (h if the electron is in I2); the column keeps its global index.
+            // A lane takes one (i, e) term for FOUR consecutive slots (16-byte LDS reads): a quarter of the iterations of the
+            // one-slot-per-lane form, which was bound by the latency of its reads with one wave per SIMD (280 k of 1.89 M cycles
+            // per workgroup).  Slots 0 and 1 (value, Laplacian) do not enter the sum; padding slots hold zeros.
+            {
+                typedef T vec4 __attribute__((ext_vector_type(4), aligned(16)));
+                const int d4 = tid & 3, g4 = tid >> 2;
+                constexpr int NG4 = NTHR / 4;
+                const bool skip01 = st == 0 && d4 == 0;
+                auto ld4 = [&](int row, int col) { return *reinterpret_cast<const vec4*>(Y + ((size_t)row * n2 + col) * 16 + 4 * d4); };
+                auto term = [&](int ri, int ci, int re_, int ce, T wgt) {      // w * Y[ri][ci] * Y[re_][ce], complex, four slots
+                    const vec4 ar = ld4(ri, 2 * ci), ai = ld4(ri, 2 * ci + 1), br = ld4(re_, 2 * ce), bi = ld4(re_, 2 * ce + 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!(skip01 && j < 2)) y2 = cx_fma(wgt * Cx<T>(ar[j], ai[j]), Cx<T>(br[j], bi[j]), y2);
+                };
+                if (pass == 1) {      // i in I1 (rows still from pass A, columns C2), e in I2 (rows from pass B, columns C1): weight 2
+#pragma unroll 3
+                    for (int pi = g4; pi < h * h; pi += NG4) {
+                        const int i = pi / h, e = h + pi % h;
+                        term(i, e, e - h, i, T(2));
+                    }
+                } else {              // upper triangle of the diagonal block (electrons off .. off + h - 1)
+                    const int off = pass == 0 ? 0 : h;
+                    for (int r = g; r < h; r += NG)      // the trace of this block, one slot per lane as the reduction below expects
+                        trc = trc + Cx<T>(Y[((size_t)r * n2 + 2 * (off + r)) * 16 + d], Y[((size_t)r * n2 + 2 * (off + r) + 1) * 16 + d]);
+                    // rows r and h-1-r of the triangle hold h+1 entries together: a rectangle (h/2) x (h+1), no search
+#pragma unroll 3
+                    for (int pi = g4; pi < (h / 2) * (h + 1); pi += NG4) {
+                        const int rr = pi / (h + 1), tt = pi - rr * (h + 1);
+                        const int r = tt < h - rr ? rr : h - 1 - rr, t = tt < h - rr ? tt : tt - (h - rr);
+                        const int i = off + r, e = off + r + t;
+                        term(r, e, e - off, i, i != e ? T(2) : T(1));
                     }
                 }
             }

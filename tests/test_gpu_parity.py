@@ -390,6 +390,24 @@ def test_value_chain_log_det_propagates_nan():
     assert torch.equal(x1[2], x0[2]) and abs(float(pm) - 0.75) < 1e-12
 
 
+def test_row_split_trace_kernel_float64():
+    """32 x 32 matrices in float64: the only size at which the row-split trace kernel (k_det_trace_mfma_split, the kernel of the
+    float32 diamond benchmark) runs in double precision -- no fixture has it.  One walker of a charged, spin-polarised bcc-Li 2x2x2
+    cell with 32 + 16 electrons (48: ten slot tiles) and two determinants against the forward-Laplacian oracle."""
+    from deepsolid_amd import hamiltonian, network, systems
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('bcc_li', S=(2, 2, 2), nelec=(32, 16))
+    net_kw = dict(systems.DETNET_DEFAULTS)
+    net_kw['determinants'] = 2
+    params = make_test_params(5, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    dp = dev_params(params)
+    xn = systems.synthetic_walkers(cell, 2, seed=3)
+    net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    ke, _ = hamiltonian.local_energy_seperate(net.apply, cell)(dp, torch.as_tensor(xn, device='cuda'))
+    ref = complex(ofl.stages(onet.params_to_torch(params), tt(xn[0]), klist, cell, net_kw)['ke'])
+    assert abs(complex(ke[0].cpu()) - ref) < 1e-8 * max(1.0, abs(ref)), (complex(ke[0].cpu()), ref)
+
+
 @pytest.mark.parametrize('name,dtype', [('graphene', torch.float64), ('diamond', torch.float64), ('diamond', torch.float32)])
 def test_log_det_one_lane_per_row_lu(name, dtype, monkeypatch):
     """Matrices of 24 x 24 and 48 x 48 (log psi only): the register LU with one lane per row (k_det_lu_wave) against the
