@@ -338,8 +338,6 @@ def main():
     orb_name = gemm_instance(n_e, dtype, 5)[0]
     if nb == 4 and st <= 5 and oc % 256 != 0 and oc % 192 == 0:           # the 48-column-per-wave instance
         orb_name = orb_name.replace(f',{nb},{st},5>', f',3,{st},5>')
-    if os.environ.get('DS_LAYER_GROUPS', '0') not in ('', '0'):
-        hidden_name = 'k_layer_unit<%s,true,2,false> + k_layer_fin' % ('double' if dtype == torch.float64 else 'float')
     # the roofline object describes the kernel with the largest share of the step
     ms_hidden, n_launch = prof['single_hidden']
     flops_total = f_layer * args.batch * n_hidden * args.steps           # this rank, timed region

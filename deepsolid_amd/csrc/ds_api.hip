@@ -13,7 +13,6 @@
 
 #include "../../include/deepsolid_hip.h"
 #include "ds_grad.h"
-#include "ds_layer.h"
 #include "ds_mcmc.h"
 
 namespace {
@@ -49,8 +48,6 @@ void inv3(const double* a, double* o) {
 // per-walker workspace carve, in elements
 struct WsLayout {
     size_t G, MEAN, ZB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
-    size_t M2V = 0;                                        // partner sums of the pair stream as 5-jets (ds_layer.h)
-    size_t LAY = 0;                                        // per-electron arrays of the layer kernels: y, y' z_L, slot-tile sums of squares
     size_t PARTM = 0;                                      // value chain: per-tile segment sums of the pair layer (k_two_layer)
     size_t mout_off[2], minv_off[2], dets_off[2], tr_off[2];
     size_t per_walker;                                     // total elements per walker
@@ -79,12 +76,8 @@ struct ds_system {
     bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
-    bool lg_gather = false;           // DS_LG_GATHER=1: hidden layers gather the pair-mean rows too (layer 0 always does)
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
-    int lg_ring = 2;                  // DS_LG_RING: operand ring depth of k_layer_group (2 or 4)
-    int lg_dbg = 0;                   // DS_LG_DBG (timing experiments, wrong results)
-    size_t lg_pad_lds = 0;            // DS_LG_PAD_LDS (experiment): extra dynamic LDS per workgroup of k_layer_group
-    bool layer_groups = false;        // DS_LAYER_GROUPS=1: electron-group layer kernels (ds_layer.h) instead of the per-electron k_jet_gemm path
+    int dbg = 0;                      // DS_DBG (kernel development): 32 = phase stamps of one wave; 1 / 2 switch arithmetic off in a `make EXP=1` build only
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
@@ -190,9 +183,6 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
             for (int j = 0; j < 3; ++j) gidx[3 * (size_t)g + j] += goff[j] - nmin[j];
     } else glen = 0;
     size_t o_gi = push(gidx.data(), integral ? gidx.size() : 0);
-    const double zero_word[4] = {0, 0, 0, 0};
-    size_t o_zero = push(zero_word, 4);
-    S.zero = (const T*)o_zero;
     S.gidx = (const T*)o_gi; S.g_len = glen;
     for (int j = 0; j < 3; ++j) { S.g_nmin[j] = nmin[j]; S.g_off[j] = goff[j]; }
     // offsets are turned into pointers after the upload
@@ -226,15 +216,6 @@ void fill_tables(ds_system* s, const ds_system_desc* d, ds::SysDev<T>& S, std::v
     S.nparam[0] = S.norb[0] * d->n_det; S.nparam[1] = d->n_dn ? S.norb[1] * d->n_det : 0;
     S.nparam_max = std::max(S.nparam[0], S.nparam[1]);
     S.ocols[0] = rup(2 * S.nparam[0], 64); S.ocols[1] = rup(2 * S.nparam[1], 64);
-    // electron groups of the layer kernels: consecutive electrons of one spin, at most LG_GE each
-    S.n_groups = 0;
-    for (int sp = 0; sp < S.nch; ++sp) {
-        const int i0 = sp == 0 ? 0 : d->n_up, ns = sp == 0 ? d->n_up : d->n_dn;
-        for (int e = 0; e < ns && S.n_groups < DS_MAXG; e += ds::LG_GE) {
-            S.grp_e0[S.n_groups] = i0 + e; S.grp_n[S.n_groups] = std::min(ds::LG_GE, ns - e); S.grp_sp[S.n_groups] = sp;
-            ++S.n_groups;
-        }
-    }
     S.As = d->n_atoms_sim; S.NG = d->n_g; S.dist_mode = d->dist_mode;
     S.alpha = (T)d->ewald_alpha; S.ee_const = (T)d->ee_const; S.ei_const = (T)d->ei_const; S.ii_total = (T)d->ii_total;
     (void)s;
@@ -244,7 +225,7 @@ template <typename T> void relocate(ds::SysDev<T>& S, const T* base) {
     auto fix = [&](const T*& p) { p = base + (size_t)p; };
     fix(S.prim_a); fix(S.prim_ainv); fix(S.sim_a); fix(S.sim_ainv); fix(S.prim_AV); fix(S.prim_BV); fix(S.sim_AV);
     fix(S.sim_BV); fix(S.atoms); fix(S.klist[0]); fix(S.klist[1]); fix(S.sim_atoms); fix(S.sim_charges); fix(S.disp27);
-    fix(S.shift27); fix(S.gpoints); fix(S.gweight); fix(S.ion_re); fix(S.ion_im); fix(S.gidx); fix(S.zero);
+    fix(S.shift27); fix(S.gpoints); fix(S.gweight); fix(S.ion_re); fix(S.ion_im); fix(S.gidx);
 }
 
 template <typename T> ds::SysDev<T>& dev(ds_system* s);
@@ -284,9 +265,7 @@ void build_layouts(ds_system* s) {
     int h1max = 0, h2max = 0;
     for (int l = 0; l <= S.n_layers; ++l) { h1max = std::max(h1max, S.h1[l]); h2max = std::max(h2max, S.h2[l]); }
     w.G = (size_t)S.N * S.ldk * S.P;
-    w.MEAN = (size_t)S.n_groups * h1max * S.P;       // (>= nch: also holds the per-group partial spin means of a layer's output)
-    w.M2V = (size_t)rup(S.N * S.nch * h2max * 5, 16);
-    w.LAY = (size_t)S.N * h1max * (2 + S.P / 16);
+    w.MEAN = (size_t)S.nch * h1max * S.P;
     w.ZB = (size_t)std::max(h1max, std::max(S.ocols[0], S.ocols[1])) * S.P;   // shared spin-mean term S of one layer / orbital head
     for (int c = 0; c < S.nch; ++c)                  // ... or the orbital GEMM output of one spin
         w.ZB = std::max(w.ZB, (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * S.P);
@@ -302,7 +281,7 @@ void build_layouts(ds_system* s) {
         tr += (size_t)S.K * 2 * S.P;
     }
     w.MOUT = mo; w.MINV = rup((int)mi, 16); w.DETS = rup((int)de, 16); w.TR = tr;
-    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR + w.M2V + w.LAY;
+    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR;
     // value chain: the slot axis carries PV walkers (ds_value.h)
     WsLayout& v = s->wsv;
     const size_t PV = ds::PV;
@@ -319,14 +298,14 @@ void build_layouts(ds_system* s) {
         v.mout_off[c] = mo;
         mo += (size_t)S.K * n * n * 2 * PV;
     }
-    v.MOUT = mo; v.MINV = 0; v.TR = 0; v.M2V = 0; v.LAY = 0;
+    v.MOUT = mo; v.MINV = 0; v.TR = 0;
     v.DETS = w.DETS * PV;             // DETS stays per walker
     v.PARTM = (size_t)(PV / 5) * h2max * 5 * (S.NP / 16) * ds::PM_SLOTS;
     v.per_walker = 2 * v.G + 2 * v.MEAN + v.ZB + 2 * v.H2 + v.Q + v.MOUT + v.DETS + v.PARTM;
 }
 
 template <typename T> struct Carve {
-    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR, *M2V, *LAY;
+    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR;
 };
 template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     const WsLayout& w = s->ws;
@@ -341,8 +320,6 @@ template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     c.MINV = p; p += w.MINV * Bc;
     c.DETS = p; p += w.DETS * Bc;
     c.TR = p; p += w.TR * Bc;
-    c.M2V = p; p += w.M2V * Bc;
-    c.LAY = p; p += w.LAY * Bc;
     return c;
 }
 
@@ -419,22 +396,11 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     if (stop == STOP_H2_0) return copy_out(dr, c.H2[0], (size_t)S.h2[0] * 5 * S.NP * Bc, st);
     if (stop == STOP_Q) return copy_out(dr, c.Q, L.Q * Bc, st);
     int gi = 0, hi = 0, mi = 0;       // current G / H2 / MEAN buffer
-    bool have_meanp = false;          // MEAN[1] holds the partial spin means of the current G (left by a grouped layer)
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
         if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
-        // electron-group layer kernel (ds_layer.h): pair-mean rows generated in the operand load, spin means of the output
-        // formed in the epilogue.  The per-electron path below stays for DS_LAYER_GROUPS=0 and for the stage dumps.
-        const bool grouped = s->layer_groups && K2 % 4 == 0 && Kh % 4 == 0;
-        // the pair-mean rows of the layer input: gathered from the pair stream in the operand load (layer 0 and DS_LG_GATHER=1:
-        // only the partner sums are needed), or expanded to dense jet rows of G first
-        const bool gather = grouped && (s->lg_gather || Kh % 8 != 0 || K2 % 8 != 0);
-        if (gather) {
-            ProfScope ps(s, DS_PROF_M2_EXPAND, st);
-            hipLaunchKernelGGL((ds::k_m2_means<T>), dim3(S.N, (unsigned)Bc), dim3(256), 0, st, S, c.H2[hi], K2, c.M2V, L.M2V);
-        }
         // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
-        if (!gather || stop == STOP_G0 + l) {
+        {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
             hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
                                c.H2[hi], K2, c.G[gi], Kh);
@@ -458,7 +424,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const int hin = hi;                                // the layer reads the pair stream of its own level (hi flips below)
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
         const bool res = Kh == Nout;
-        if (!grouped && res && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
+        if (res && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
             constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
             dim3 block; unsigned gz;
@@ -472,19 +438,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
                                        (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[0], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
                                        c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
-                else if (have_meanp) {
-                    // hidden layer after a grouped layer: the spin means of its input came out of that layer's epilogue
-                    // (MEANP, one partial mean per electron group); several groups per spin are folded first
-                    const T* mean = c.MEAN[1];
-                    if (S.n_groups > S.nch) {
-                        hipLaunchKernelGGL((ds::k_group_fold<T>), dim3((unsigned)((S.nch * Kh * S.P + 1023) / 1024), (unsigned)Bc), dim3(256), 0, st, S,
-                                           c.MEAN[1], L.MEAN, Kh, c.MEAN[0], L.MEAN);
-                        mean = c.MEAN[0];
-                    }
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
-                                       (size_t)0, (size_t)0, (const T*)nullptr, 0, mean, L.MEAN, blk(s->i_wsh[l]), Ksh, 0,
-                                       c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
-                } else {
+                else {
                     // (its own geometry: as many waves per workgroup as possible, every workgroup re-forms the spin means)
                     dim3 sblock; unsigned sgz;
                     gemm_geom(Nout, NB, &sblock, &sgz);
@@ -492,50 +446,23 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                                        c.G[gi], blk(s->i_wsh[l]), Kh, c.ZB, Nout, S.P, blk(s->i_b[l]), 0);
                 }
             }
-            if (grouped) {
-                ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
-                dim3 gblock; unsigned ggz;
-                gemm_geom(Nout, 4, &gblock, &ggz);
-                const size_t lay = (size_t)S.N * Nout;
-                ds::LayerArgs<T> la{c.G[gi], c.G[gi ^ 1], gws, gts, blk(s->i_wloc[l]), Kh, K2, Nout, c.ZB, c.H2[hin], (size_t)K2 * 5 * S.NP,
-                                    c.M2V, L.M2V, c.MEAN[1], L.MEAN, c.LAY, c.LAY + lay * Bc, c.LAY + 2 * lay * Bc, lay, 0, 1, S.zero,
-                                    (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) ? s->clk_dev : nullptr,
-                                    s->lg_dbg};
-                const size_t lds = ds::layer_unit_lds_bytes<T>(gblock.x) + s->lg_pad_lds;
-                const int ntile = S.P / 16;
-                const int Ktot = Kh + S.nch * K2;
-                const int pipe = gather ? 0 : ((s->lg_ring == 4 && Ktot % 16 == 0) ? 4 : (Ktot % 8 == 0 ? 2 : 0));
-                // slot tile 0 first (it produces y = tanh(z_0) of every electron), then all the other tiles, then the Laplacian slot
-                for (int part = 0; part < 2; ++part) {
-                    la.t0 = part; la.nt = part == 0 ? 1 : ntile - 1;
-                    if (la.nt < 1) continue;
-                    const dim3 ggrid(la.nt * S.n_groups * ggz, (unsigned)Bc, 1);
-#define DS_LU(RESV, PIPEV, GV) hipLaunchKernelGGL((ds::k_layer_unit<T, RESV, PIPEV, GV>), ggrid, gblock, lds, st, S, la)
-                    if (gather) { if (res) DS_LU(true, 0, true); else DS_LU(false, 0, true); }
-                    else if (res) { if (pipe == 4) DS_LU(true, 4, false); else if (pipe == 2) DS_LU(true, 2, false); else DS_LU(true, 0, false); }
-                    else { if (pipe >= 2) DS_LU(false, 2, false); else DS_LU(false, 0, false); }
-#undef DS_LU
-                }
-                if (res) hipLaunchKernelGGL((ds::k_layer_fin<T, true>), dim3(S.n_groups, (unsigned)Bc), dim3(Nout), 0, st, S, la);
-                else hipLaunchKernelGGL((ds::k_layer_fin<T, false>), dim3(S.n_groups, (unsigned)Bc), dim3(Nout), 0, st, S, la);
-            } else {
-                // ... then the N electron tiles with the fused epilogue
-                ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
-                if (res) {
-                    ds::OrbEpi<T> oe_clk{};
-                    oe_clk.dbg = s->lg_dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
-                    if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { oe_clk.clk = s->clk_dev; oe_clk.dbg = s->lg_dbg; }
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
-                                       blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
-                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), oe_clk);
-                }
-                else
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, c.G[gi], gws, gts,
-                                       blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
-                                       (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+            {
+            // ... then the N electron tiles with the fused epilogue
+            ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
+            if (res) {
+                ds::OrbEpi<T> oe_clk{};
+                oe_clk.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
+                if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { oe_clk.clk = s->clk_dev; oe_clk.dbg = s->dbg; }
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
+                                   blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
+                                   (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), oe_clk);
+            }
+            else
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, c.G[gi], gws, gts,
+                                   blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
+                                   (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
             }
         });
-        have_meanp = grouped;
         if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
         gi ^= 1;
         if (l < S.n_double) {
@@ -617,7 +544,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         if ((2 * n) % 4 == 0 && ybytes <= 160 * 1024 && nt <= 6 && !s->det_valu) {
 #define DS_TRMF(NTV, SWV, NWV, NF) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV, NF>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
-                                            L.dets_off[sp], (s->lg_dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr)
+                                            L.dets_off[sp], (s->dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr)
 #define DS_TRM(NTV, SWV, NWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp])
@@ -629,7 +556,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 const size_t sbytes = (size_t)(n / 2) * 2 * n * 16 * sizeof(T) + 512 * sizeof(ds::Cx<T>);
 #define DS_TRS(NTV) hipLaunchKernelGGL((ds::k_det_trace_mfma_split<T, NTV, NWS, (NTV <= 4 || sizeof(T) == 4 ? 2 : 1)>), dim3(S.K, (unsigned)Bc), dim3(64 * NWS), sbytes, st, S, c.MOUT, L.MOUT,  \
                                        L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS, L.dets_off[sp], \
-                                       (s->lg_dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr)
+                                       (s->dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr)
                 if (n == 32) DS_TRS(4); else DS_TRS(6);        // 2n = 16 NT exactly
 #undef DS_TRS
             } else if (sw8) { if (nt <= 4) DS_TRM(4, 8, 4); else DS_TRM(6, 8, 4); }
@@ -886,6 +813,7 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
     const ds::SysDev<T>& S = dev<T>(s);
     int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T));
     if (chunk < 1) return fail("workspace too small: %lld bytes < %zu per walker", (long long)ws_bytes, s->ws.per_walker * sizeof(T));
+    chunk = std::min<int64_t>(chunk, 65535);      // grid.y carries the walker index
     if (s->n_streams == 2 && chunk >= 2 && B > chunk / 2) {
         // two half-size workspaces, chunks alternate between two side streams
         const int64_t half = chunk / 2;
@@ -932,7 +860,7 @@ template <typename T>
 int logpsi_grad_impl(ds_system* s, const void* params, const void* x, int64_t B, void* out_logabs, void* out_phase, void* out_grad,
                      void* ws, int64_t ws_bytes, hipStream_t st) {
     const ds::SysDev<T>& S = dev<T>(s);
-    const int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T));
+    const int64_t chunk = std::min<int64_t>(ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T)), 65535);
     if (chunk < 1) return fail("workspace too small");
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t Bc = std::min(chunk, B - b0);
@@ -1382,12 +1310,9 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     s->det_half_slots = getenv("DS_DET_HALF_SLOTS") != nullptr;
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
-    if (const char* e = getenv("DS_LAYER_GROUPS")) s->layer_groups = atoi(e) != 0;
-    if (const char* e = getenv("DS_LG_PAD_LDS")) s->lg_pad_lds = (size_t)atol(e);
-    if (const char* e = getenv("DS_LG_DBG")) s->lg_dbg = atoi(e);
-    if (const char* e = getenv("DS_LG_RING")) s->lg_ring = atoi(e);
-    if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::max<int64_t>(1, atol(e));
-    if (const char* e = getenv("DS_LG_GATHER")) s->lg_gather = atoi(e) != 0;
+    if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
+    // (grid.y carries the walker index: at most 65535 walkers per launch)
+    if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::min<int64_t>(65535, std::max<int64_t>(1, atol(e)));
     if (s->n_streams == 2) {
         bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
         // DS_CUMASK=1: each side stream owns one half of the CU mask bits (experiment: chunks at different phases on disjoint CUs)
@@ -1438,10 +1363,15 @@ int ds_param_layout(const ds_system* s, ds_param_block* blocks, int max_blocks) 
 int64_t ds_workspace_bytes(const ds_system* s, int64_t B) {
     if (!s) return -1;
     const int64_t esz = s->dtype == 0 ? 8 : 4;
-    // walkers are processed in chunks: at most 4096 per chunk and at most ~80 GiB of scratch of the 288 GB (large cells need
-    // hundreds of MB per walker: 96 electrons f32 = 0.2 GB).  One 4096-walker pass instead of four 1024-walker passes is
-    // 1.5-2 % faster (fewer kernel tails) with bit-identical energies (tools/chunk_sweep.py); DS_CHUNK_WALKERS (read at create) overrides the cap.
-    const int64_t budget = (int64_t)80 << 30;
+    // walkers are processed in chunks: at most 4096 per chunk, and a scratch budget of at most 80 GiB but never more than 40 % of
+    // the device memory that is free when the caller asks (large cells need hundreds of MB per walker: 96 electrons f32 =
+    // 0.2 GB; a second DeviceSystem in the process, a smaller GPU or a caching allocator holding old buffers must not turn
+    // this into an out-of-memory error).  One 4096-walker pass instead of four 1024-walker passes is 1.5-2 % faster (fewer
+    // kernel tails) with bit-identical energies (tools/chunk_sweep.py); DS_CHUNK_WALKERS (read at create) overrides the cap.
+    int64_t budget = (int64_t)80 << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+        budget = std::min<int64_t>(budget, std::max<int64_t>((int64_t)(free_b / 10 * 4), (int64_t)1 << 30));
     const int64_t cap = s->chunk_cap;
     int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), cap);
     chunk = std::max<int64_t>(1, std::min<int64_t>(chunk, budget / ((int64_t)s->ws.per_walker * esz)));

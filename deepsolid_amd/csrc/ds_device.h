@@ -11,8 +11,8 @@
 
 #define DS_PI 3.14159265358979323846
 
-// Timing experiments that switch parts of the arithmetic OFF (tools/exp_dbg.sh, DESIGN.md section 4b) exist only in a library
-// built with `make EXP=1`: in the shipped build the DS_LG_DBG bits that would change a result are compiled out, so no
+// Timing experiments that switch parts of the arithmetic OFF (tools/exp_dbg.sh, DESIGN.md section 4) exist only in a library
+// built with `make EXP=1`: in the shipped build the DS_DBG bits that would change a result are compiled out, so no
 // environment variable can make the product path return wrong energies.  (The clock probe and the phase stamps never
 // change a result and stay.)
 #ifdef DS_TIMING_EXPERIMENTS

@@ -31,7 +31,7 @@ template <typename T> struct OrbEpi {
     // optional in-kernel clock probe (hidden layers, EPI = 2, while profiling): wave 0 of every workgroup adds its shader-clock
     // cycles (s_memtime) to clk[0] and its constant-rate 100 MHz ticks (s_memrealtime) to clk[1]
     unsigned long long* clk;
-    int dbg;                        // DS_LG_DBG & 32 (kernel development): one wave also writes phase stamps to clk[2 + i]
+    int dbg;                        // DS_DBG & 32 (kernel development): one wave also writes phase stamps to clk[2 + i]
 };
 
 // Residual stash (EPI = 2 / 4): the residual rows of a layer are rows n0..n0+16*NB-1 of the SAME tile the wave streams as

@@ -22,7 +22,6 @@
 namespace ds {
 
 #define DS_MAXL 8
-#define DS_MAXG 16            // electron groups of the layer kernels (ds_layer.h): <= 12 electrons of one spin each
 
 template <typename T> struct SysDev {
     int N, n_up, n_dn, A, L, K, nch;
@@ -50,9 +49,6 @@ template <typename T> struct SysDev {
     // g_len = table entries per electron (0: no tables, direct sincos per (G, electron))
     const T* gidx;
     int g_nmin[3], g_off[3], g_len;
-    const T* zero;                // one element holding 0 (ds_layer.h: B operand of lanes that contribute nothing)
-    // electron groups of k_layer_group (ds_layer.h): group g = electrons grp_e0[g] .. + grp_n[g] - 1, all of spin grp_sp[g]
-    int n_groups, grp_e0[DS_MAXG], grp_n[DS_MAXG], grp_sp[DS_MAXG];
 };
 // dynamic LDS of k_ewald: walker coordinates + two reduction arrays + the per-electron phase tables
 template <typename T> inline size_t ewald_lds_bytes(const SysDev<T>& S) {

@@ -271,7 +271,7 @@ int ds_profile_read(ds_system* sys, double* ms_total, int64_t* launches);
  * clock the kernel actually ran at in that region (the MFMA peak scales with it). */
 int ds_profile_read_clock(ds_system* sys, double* shader_cycles, double* ref_ticks);
 /* Kernel-development aid: shader-clock stamps written by one wave of the hidden-layer kernel at its phase boundaries when the
- * library runs with DS_LG_DBG=32 and profiling is enabled (tools/layer_timeline.py); n <= 1022 stamps. */
+ * library runs with DS_DBG=32 and profiling is enabled (tools/gemm_timeline.py); n <= 1022 stamps. */
 int ds_debug_timeline(ds_system* sys, uint64_t* out, int n);
 
 /* Calibration kernel for the rocprofv3 FETCH_SIZE / WRITE_SIZE counters: copies n_elems float64

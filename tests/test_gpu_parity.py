@@ -245,65 +245,18 @@ def test_kinetic_energy_vs_reference_hamiltonian(name):
     np.testing.assert_allclose(ew, fx['ew_ref'], atol=1e-9 * max(1.0, np.abs(fx['ew_ref']).max()))
 
 
-@pytest.mark.parametrize('name', ['lih', 'lih_mixed', 'lih_narrow', 'li_polarized', 'bcc_li', 'bcc_li_fulldet', 'graphene'])
-def test_per_electron_layer_path_vs_reference_hamiltonian(name, monkeypatch):
-    """The one-electron layers have two device paths: the electron-group kernels of csrc/ds_layer.h (default; every other
-    test runs them) and the per-electron k_jet_gemm + k_shared_term + k_m2_expand path (DS_LAYER_GROUPS=0, read at system
-    creation).  The second must reproduce the reference-executed kinetic energies too, and both must agree to rounding."""
-    from deepsolid_amd.device import DeviceSystem
-    from deepsolid_amd.ewaldsum import EwaldTables
-    fx, cell, klist, net_kw, params = load_case(name)
-    dp = dev_params(params)
-    nw = len(fx['ke_ref'])
-    x = torch.as_tensor(fx['x'][:nw], device='cuda')
-    out = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('DS_LAYER_GROUPS', flag)
-        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
-        ke = sysd.local_energy(dp, x)[0]
-        out[flag] = torch.view_as_complex(ke).cpu().numpy()
-        for b in range(nw):
-            assert abs(out[flag][b] - fx['ke_ref'][b]) < 1e-9 * max(1.0, abs(fx['ke_ref'][b])), (flag, b, out[flag][b], fx['ke_ref'][b])
-    assert np.abs(out['1'] - out['0']).max() < 1e-10 * max(1.0, np.abs(out['0']).max())
-
-
-@pytest.mark.parametrize('name', ['lih', 'bcc_li'])
-def test_electron_group_layer_path_float32(name, monkeypatch):
-    """The float32 instantiation of the electron-group layer kernels (DS_LAYER_GROUPS=1; the accumulator <-> slot maps differ
-    from float64): E_kin against the float64 oracle at the float32-rounded walker, tolerance of the default float32 chain
-    (test_float32_chain_vs_float64_oracle: 1e-4 relative), and agreement with the default float32 path to the same."""
-    from deepsolid_amd.device import DeviceSystem
-    from deepsolid_amd.ewaldsum import EwaldTables
-    fx, cell, klist, net_kw, params = load_case(name)
-    dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
-    p_cpu = onet.params_to_torch(params)
-    x = torch.as_tensor(fx['x'][:2], dtype=torch.float32, device='cuda')
-    out = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('DS_LAYER_GROUPS', flag)
-        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float32)
-        out[flag] = torch.view_as_complex(sysd.local_energy(dp, x)[0].double()).cpu().numpy()
-    for b in range(2):
-        ref = complex(ofl.stages(p_cpu, x[b].cpu().double(), klist, cell, net_kw)['ke'])
-        for flag in ('1', '0'):
-            assert abs(out[flag][b] - ref) < 1e-4 * max(1.0, abs(ref)), (flag, b, out[flag][b], ref)
-
-
-@pytest.mark.parametrize('groups', ['0', '1'])
-def test_debug_switches_cannot_change_results(groups, monkeypatch):
-    """The kernel-development switches (DS_LG_DBG: skip the epilogue, start the accumulators at zero, shorten the k-loops,
-    ...) exist only in a library built with `make EXP=1`.  In the shipped build they are compiled out: with every bit set
-    the energies of both layer paths are BIT-identical to a run without them (the remaining bits -- clock probe, phase
-    stamps, start skew -- only time things)."""
+def test_debug_switches_cannot_change_results(monkeypatch):
+    """The kernel-development switches (DS_DBG: skip the epilogue, start the accumulators at zero) exist only in a library
+    built with `make EXP=1`.  In the shipped build they are compiled out: with every bit set the energies are BIT-identical
+    to a run without them (the remaining bits -- clock probe, phase stamps -- only time things)."""
     from deepsolid_amd.device import DeviceSystem
     from deepsolid_amd.ewaldsum import EwaldTables
     fx, cell, klist, net_kw, params = load_case('bcc_li')
     dp = dev_params(params)
     x = torch.as_tensor(fx['x'][:4], device='cuda')
-    monkeypatch.setenv('DS_LAYER_GROUPS', groups)
-    monkeypatch.delenv('DS_LG_DBG', raising=False)
+    monkeypatch.delenv('DS_DBG', raising=False)
     ref = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).local_energy(dp, x)[0]
-    monkeypatch.setenv('DS_LG_DBG', str(1 | 2 | 4 | 64 | 128 | 256 | 512))
+    monkeypatch.setenv('DS_DBG', str(1 | 2 | 4 | 64 | 128 | 256 | 512))
     got = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).local_energy(dp, x)[0]
     assert torch.equal(ref, got)
     for b in range(4):

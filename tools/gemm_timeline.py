@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""GPU box: phase stamps of one wave of the hidden-layer k_jet_gemm (DS_LG_DBG=32): start, operands ready, products done, end."""
+"""GPU box: phase stamps of one wave of the hidden-layer k_jet_gemm (DS_DBG=32): start, operands ready, products done, end."""
 import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-os.environ.setdefault('DS_LG_DBG', '32')
+os.environ.setdefault('DS_DBG', '32')
 from deepsolid_amd import hamiltonian, network, systems
 cell, klist = systems.build('bcc_li')
 net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **systems.DETNET_DEFAULTS)

@@ -18,7 +18,7 @@ python - "$TAG" <<'PY'
 import csv, glob, json, os, sys
 from collections import defaultdict
 root = 'gpurun_out/pmc_' + sys.argv[1]
-pat = os.environ.get('PMC_KERNELS', 'k_layer_group,k_jet_gemm<double, 4, 5, 2>,k_jet_gemm<double, 4, 5, 1>').split(',')
+pat = os.environ.get('PMC_KERNELS', 'k_jet_gemm<double, 4, 5, 2>,k_jet_gemm<double, 4, 5, 1>').split(',')
 tot, cnt = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
 for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
     for row in csv.DictReader(open(f)):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: per-phase shader-clock totals of one workgroup of the trace kernel (k_det_trace_mfma_split for diamond float32, the default;
-k_det_trace_mfma for `python tools/trace_timeline.py 1024 bcc_li f64` or `512 graphene f64`; DS_LG_DBG=32):
+k_det_trace_mfma for `python tools/trace_timeline.py 1024 bcc_li f64` or `512 graphene f64`; DS_DBG=32):
 fragment setup, products, barrier after them, pair sums, barrier after them, per-tile trace reduction, whole kernel -- per wave."""
 import ctypes as C
 import os
@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-os.environ['DS_LG_DBG'] = '32'
+os.environ['DS_DBG'] = '32'
 from deepsolid_amd import hamiltonian, network, systems
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 name = sys.argv[2] if len(sys.argv) > 2 else 'diamond'
