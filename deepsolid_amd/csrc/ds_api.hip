@@ -49,6 +49,7 @@ void inv3(const double* a, double* o) {
 struct WsLayout {
     size_t G, MEAN, ZB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
     size_t PARTM = 0;                                      // value chain: per-tile segment sums of the pair layer (k_two_layer)
+    size_t XL = 0;                                         // layer-0 input tiles [N][h1[0] + nch h2[0]][P] (low-rank first hidden layer)
     size_t mout_off[2], minv_off[2], dets_off[2], tr_off[2];
     size_t per_walker;                                     // total elements per walker
 };
@@ -77,6 +78,8 @@ struct ds_system {
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
+    bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
+    void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
     int dbg = 0;                      // DS_DBG (kernel development): 32 = phase stamps of one wave; 1 / 2 switch arithmetic off in a `make EXP=1` build only
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -281,7 +284,8 @@ void build_layouts(ds_system* s) {
         tr += (size_t)S.K * 2 * S.P;
     }
     w.MOUT = mo; w.MINV = rup((int)mi, 16); w.DETS = rup((int)de, 16); w.TR = tr;
-    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR;
+    w.XL = (size_t)S.N * (S.h1[0] + S.nch * S.h2[0]) * S.P;
+    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR + w.XL;
     // value chain: the slot axis carries PV walkers (ds_value.h)
     WsLayout& v = s->wsv;
     const size_t PV = ds::PV;
@@ -305,7 +309,7 @@ void build_layouts(ds_system* s) {
 }
 
 template <typename T> struct Carve {
-    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR;
+    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR, *XL;
 };
 template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     const WsLayout& w = s->ws;
@@ -320,6 +324,7 @@ template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     c.MINV = p; p += w.MINV * Bc;
     c.DETS = p; p += w.DETS * Bc;
     c.TR = p; p += w.TR * Bc;
+    c.XL = p; p += w.XL * Bc;
     return c;
 }
 
@@ -385,12 +390,23 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     Carve<T> c = carve<T>(s, ws, Bc);
     auto blk = [&](int i) { return params + s->blocks[i].offset; };
     const int stop = dr ? dr->stop : STOP_NONE;
+    // Low-rank first hidden layer (k_layer1_lr): layer 0 reads its input tiles from their own buffer XL (layer 1 needs them again
+    // while it overwrites G[0]); off for the stage dumps, which show the dense path's buffers.
+    const int K0loc = S.h1[0] + S.nch * S.h2[0], K0sh = S.nch * S.h1[0];
+    const int lr_nc = std::max(2, (K0loc + K0sh + 4 + 15) / 16);      // column tiles of the per-electron weights C (instances: 2, 3, 4)
+    const bool lr_on = s->use_lr && !dr && S.n_layers >= 2 && lr_nc <= 4 && S.h1[1] % 16 == 0 && (S.nch * S.h2[1]) % 4 == 0 &&
+                       3 * (K0loc + K0sh + 4) <= S.h1[1];
     // 1. features
     {
         ProfScope ps(s, DS_PROF_FEATURES, st);
         size_t sh = (size_t)(9 * S.N) * sizeof(T) + (size_t)S.N * S.A * S.nf * sizeof(ds::Jet5<T>);
         hipLaunchKernelGGL((ds::k_features<T>), dim3((unsigned)Bc), dim3(256), sh, st, S, x, blk(s->i_pi[0]), blk(s->i_sg[0]),
-                           blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), c.G[0], c.MEAN[0], c.H2[0], c.Q);
+                           blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), lr_on ? c.XL : c.G[0], lr_on ? K0loc : S.ldk, c.MEAN[0], c.H2[0], c.Q);
+    }
+    if (lr_on) {
+        const int n = S.h1[1] * 16 * lr_nc;
+        hipLaunchKernelGGL((ds::k_lr_w0t<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, blk(s->i_wloc[0]), blk(s->i_wsh[0]), K0loc, K0sh,
+                           S.h1[1], 16 * lr_nc, (T*)s->lr_w0t);
     }
     if (stop == STOP_MEAN0) return copy_out(dr, c.MEAN[0], (size_t)S.nch * S.h1[0] * S.P * Bc, st);
     if (stop == STOP_H2_0) return copy_out(dr, c.H2[0], (size_t)S.h2[0] * 5 * S.NP * Bc, st);
@@ -402,8 +418,9 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
         {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
+            const bool xl = lr_on && l == 0;
             hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
-                               c.H2[hi], K2, c.G[gi], Kh);
+                               c.H2[hi], K2, xl ? c.XL : c.G[gi], Kh, xl ? K0loc : S.ldk);
         }
         if (stop == STOP_G0 + l) return copy_out(dr, c.G[gi], L.G * Bc, st);
         // pair stream layer
@@ -437,7 +454,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 if (l == 0)
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
                                        (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[0], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
-                                       c.ZB, (size_t)Nout * S.P, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                                       c.ZB, (size_t)Nout * S.P, (size_t)0, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
                 else {
                     // (its own geometry: as many waves per workgroup as possible, every workgroup re-forms the spin means)
                     dim3 sblock; unsigned sgz;
@@ -449,18 +466,30 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             {
             // ... then the N electron tiles with the fused epilogue
             ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
-            if (res) {
+            // layer input tiles: G[gi], or (layer 0 in front of the low-rank layer 1) the XL buffer
+            const T* Xin = (lr_on && l == 0) ? c.XL : c.G[gi];
+            const size_t xws = (lr_on && l == 0) ? (size_t)S.N * K0loc * S.P : gws, xts = (lr_on && l == 0) ? (size_t)K0loc * S.P : gts;
+            if (lr_on && l == 1) {
+                // first hidden layer on the low-rank form of the layer-0 output (ds_gemm.h: k_layer1_lr)
+                ds::LrArgs<T> la{c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, c.MEAN[0], (size_t)K0sh * S.P, K0loc, K0sh,
+                                 (const T*)s->lr_w0t, c.G[gi], gws, gts, blk(s->i_wloc[l]), Kh, S.nch * K2, c.G[gi ^ 1], gws, gts, c.ZB,
+                                 Nout, S.P, S.N};
+                const dim3 lgrid(S.N * gz, (unsigned)Bc, 1);
+#define DS_LR(NCV, RESV) hipLaunchKernelGGL((ds::k_layer1_lr<T, NB, ST, NCV, RESV>), lgrid, block, (ds::lr_lds_bytes<T, NB, NCV>(block.x, Kh)), st, la)
+                if (lr_nc <= 2) { if (res) DS_LR(2, true); else DS_LR(2, false); }
+                else if (lr_nc == 3) { if (res) DS_LR(3, true); else DS_LR(3, false); }
+                else { if (res) DS_LR(4, true); else DS_LR(4, false); }
+#undef DS_LR
+            } else if (res) {
                 ds::OrbEpi<T> oe_clk{};
                 oe_clk.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { oe_clk.clk = s->clk_dev; oe_clk.dbg = s->dbg; }
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, c.G[gi], gws, gts,
-                                   blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
-                                   (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), oe_clk);
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, Xin, xws, xts,
+                                   blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1], gws, gts, Nout, S.P, c.ZB, blk(s->i_b[l]), oe_clk);
             }
             else
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, c.G[gi], gws, gts,
-                                   blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1],
-                                   (size_t)0, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, Xin, xws, xts,
+                                   blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1], gws, gts, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
             }
         });
         if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
@@ -476,7 +505,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     if (s->use_last) {
         ProfScope ps(s, DS_PROF_M2_EXPAND, st);
         hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2l, S.N)), dim3(256), (size_t)(K2l * 5 * S.N + S.nch * K2l * 5) / m2_split<T>(K2l, S.N) * sizeof(T), st, S,
-                           c.H2[hi], K2l, c.G[gi], Kl);
+                           c.H2[hi], K2l, c.G[gi], Kl, S.ldk);
     }
     for (int sp = 0; sp < S.nch; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
@@ -503,12 +532,12 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 hipLaunchKernelGGL((ds::k_jet_gemm<T, 3, (ST <= 5 ? ST : 1), 5>), dim3(ns * gz3, (unsigned)Bc, 1), b3, 0, st,
                                    c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
                                    blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
-                                   (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
+                                   (size_t)0, (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
             } else
             hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 5>), dim3(ns * gz, (unsigned)Bc, 1), block, 0, st,
                                c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
                                blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
-                               (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
+                               (size_t)0, (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
         });
         if (rc) return fail("no orbital kernel instance for %d slot tiles", S.P / 16);
     }
@@ -674,7 +703,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         gemm_geom(Nout, 4, &block, &gz);
         if (l == 0)
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 7>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
-                               (const T*)nullptr, 0, vb.MEAN0, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
+                               (const T*)nullptr, 0, vb.MEAN0, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, (size_t)0, Nout, PV,
                                (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
         else {
             // hidden layers: spin means over the electrons in a bandwidth-bound pass that fills the chip (a group is one
@@ -684,15 +713,15 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
             // of Ksh/4 x 20 MFMAs (75 us at Ksh = 512).  16-feature waves in 64-feature workgroups: four times the waves on four
             // times the CUs, a quarter of the chain each (same products in the same order: bit-identical)
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 1, 5, 7>), dim3(1, (unsigned)ng, (unsigned)(Nout / 64)), dim3(256), 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
-                               (const T*)nullptr, 0, vb.MEANS, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, Nout, PV,
+                               (const T*)nullptr, 0, vb.MEANS, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, (size_t)0, Nout, PV,
                                (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
         }
         if (Kh == Nout)
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, (ds::gemm_stash_bytes<T, 4, 5>(block.x)), st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
-                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, gws, gts, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
         else
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 3>), dim3(S.N, (unsigned)ng, gz), block, 0, st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
-                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, (size_t)0, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, gws, gts, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
     }
     T* Gl = vb.Gl[S.n_layers];
     const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
@@ -713,7 +742,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         if (vb.MINV) {
             // gradient pass: the raw products PHI are kept (k_orbital_bwd reads them), the product with q is its own kernel
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, ogz), oblock, 0, st, Gl + (size_t)i0 * S.ldk * PV,
-                               gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, vb.PHI[sp], (size_t)ns * OC * PV,
+                               gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, vb.PHI[sp], (size_t)ns * OC * PV, (size_t)0,
                                OC, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
             hipLaunchKernelGGL((ds::k_orbital_epilogue_val<T>), dim3(ns, (unsigned)ng), dim3(256), 0, st, S, vb.PHI[sp], (size_t)ns * OC * PV, Q, MOUT, sp,
                                L.MOUT, L.mout_off[S.mat_ch[sp]], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr,
@@ -724,7 +753,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         ds::OrbEpi<T> oe{Q, MOUT, L.MOUT, L.mout_off[S.mat_ch[sp]], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[S.mat_ch[sp]],
                          S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
 #define DS_VORB(NBV, BLK, GZ) hipLaunchKernelGGL((ds::k_jet_gemm<T, NBV, 5, 8>), dim3(ns, (unsigned)ng, GZ), BLK, 0, st, Gl + (size_t)i0 * S.ldk * PV, \
-                           gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr, (size_t)0, \
+                           gws, gts, blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr, (size_t)0, (size_t)0, \
                            OC, PV, s->use_last ? (const T*)Sorb : (const T*)nullptr, (const T*)nullptr, oe)
         // 192 columns would be three 64-column waves per workgroup: 48-column waves give four balanced ones (as in the
         // forward-Laplacian chain's orbital head): 131 -> 94 us per 4096 bcc-Li walkers
@@ -1029,7 +1058,7 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
             gemm_geom(Kop, 4, &block, &gz);
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(ns, (unsigned)ng, gz), block, 0, st, PB[sp], pgs, (size_t)OC * PV,
                                WT + gp.worbT[sp], OC, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, GBAR + (size_t)i0 * Kop * PV,
-                               (size_t)S.N * Kop * PV, Kop, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                               (size_t)S.N * Kop * PV, (size_t)0, Kop, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
             if (s->use_last) {
                 // shared term of the orbital head (network.py:535): S_orb = W_sh^T mean_i h_i, one per spin channel
                 const int Ksh = S.nch * Kl;
@@ -1042,7 +1071,7 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
                 gemm_geom(Ksh, 4, &block, &gz);
                 hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
                                    (const T*)nullptr, 0, SBAR, (size_t)OC * PV, WT + gp.wshorbT[sp], OC, 0, sp == 0 ? MEANBAR : MEANBAR2,
-                                   (size_t)Ksh * PV, Ksh, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                                   (size_t)Ksh * PV, (size_t)0, Ksh, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
             }
         }
         hipLaunchKernelGGL((ds::k_env_grad<T>), dim3((unsigned)ng, S.nch), dim3(256), 0, st, S, x, (long)Bc, vb.Gl[0], QBAR,
@@ -1079,11 +1108,11 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
                 gemm_geom(Kpad, 4, &block, &gz);
                 hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(S.N, (unsigned)ng, gz), block, 0, st, ZBAR, (size_t)S.N * Nout * PV,
                                    (size_t)Nout * PV, WT + gp.wlocT[l], Nout, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, GBAR,
-                                   (size_t)S.N * Kpad * PV, Kpad, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                                   (size_t)S.N * Kpad * PV, (size_t)0, Kpad, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
                 gemm_geom(Ksh, 4, &block, &gz);
                 hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 0>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0,
                                    (size_t)0, (const T*)nullptr, 0, SBAR, (size_t)Nout * PV, WT + gp.wshT[l], Nout, 0, MEANBAR,
-                                   (size_t)Ksh * PV, Ksh, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
+                                   (size_t)Ksh * PV, (size_t)0, Ksh, PV, (const T*)nullptr, (const T*)nullptr, ds::OrbEpi<T>{});
             }
             // pair stream
             const dim3 pgrid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
@@ -1299,6 +1328,14 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     relocate<double>(s->sd, (const double*)s->blob64);
     relocate<float>(s->sf, (const float*)s->blob32);
     build_layouts(s);
+    {
+        int h1max = 0;
+        for (int l = 0; l <= s->sd.n_layers; ++l) h1max = std::max(h1max, s->sd.h1[l]);
+        if (hipMalloc(&s->lr_w0t, (size_t)h1max * 64 * sizeof(double)) != hipSuccess) {
+            ds_system_destroy(s);
+            return fail("hipMalloc of the low-rank layer's weight table failed");
+        }
+    }
     if (hipMalloc((void**)&s->clk_dev, 1024 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(s->clk_dev, 0, 1024 * sizeof(unsigned long long)) != hipSuccess) {
         ds_system_destroy(s);
@@ -1310,6 +1347,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     s->det_half_slots = getenv("DS_DET_HALF_SLOTS") != nullptr;
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
+    s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     // (grid.y carries the walker index: at most 65535 walkers per launch)
     if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::min<int64_t>(65535, std::max<int64_t>(1, atol(e)));
@@ -1346,6 +1384,7 @@ void ds_system_destroy(ds_system* s) {
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->clk_dev) (void)hipFree(s->clk_dev);
+    if (s->lr_w0t) (void)hipFree(s->lr_w0t);
     if (s->blob64) (void)hipFree(s->blob64);
     if (s->blob32) (void)hipFree(s->blob32);
     delete s;

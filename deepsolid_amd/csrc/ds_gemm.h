@@ -62,10 +62,95 @@ template <typename T, int NB, int ST> constexpr int ring_sets() {
 // layer 0 (K = 12, 8, ...) use the plain loop.
 __host__ __device__ constexpr bool gemm_uses_ring(int epi) { return epi == 0 || epi == 2 || epi == 4 || epi == 5 || epi == 8; }
 
+// Fused one-electron-layer epilogue (network.py:524-528) on a wave's accumulator tile: rows n0 + 16 a + acc_row(lane, r),
+// slots 16 s + lr.  EPI 1 / 2: tanh chain rule on the jets without / with the residual; EPI 3 / 4: plain tanh (value chain).
+//   Gi: residual rows of the tile (+ lr), row stride P;  Go: output tile (+ lr), row stride P;  stash: the wave's LDS copy of the
+//   first NA 16-row blocks of its residual rows (stash_blocks), the others are re-read from Gi.
+template <typename T, int NB, int ST, int EPI, int NA>
+__device__ __forceinline__ void layer_epilogue(typename Acc4<T>::type (&acc)[NB][ST], const T* __restrict__ Gi, T* __restrict__ Go,
+                                               const T* stash, int n0, int lane, int P) {
+    constexpr bool RESID = EPI == 2 || EPI == 4;
+    const int lr = lane & 15;
+    const T rs2 = T(0.70710678118654752440);
+    // Row groups q = 4a + r (4 rows x P slots each) are independent.  The residual of the first NQL groups comes from
+    // the LDS stash; the others are re-read from memory, up to DEPTH groups in flight, and those loads are issued
+    // before the stash rows are worked on, so their latency overlaps that arithmetic.
+    constexpr int NQ = NB * 4, NQL = NA * 4, NQG = RESID ? NQ - NQL : 0, DMAX = 40 / (ST * (int)sizeof(T) / 4) > 1 ? 40 / (ST * (int)sizeof(T) / 4) : 1,
+                  DEPTH = NQG < DMAX ? NQG : DMAX;      // about 40 VGPRs of loads in flight
+    T hq[DEPTH > 0 ? DEPTH : 1][ST];
+    auto fetch = [&](int q, int slot) {
+        const int n = n0 + 16 * (q >> 2) + acc_row<T>(lane, q & 3);
+#pragma unroll
+        for (int s = 0; s < ST; ++s) hq[slot][s] = Gi[n * P + 16 * s];
+    };
+#pragma unroll
+    for (int g = 0; g < DEPTH; ++g) fetch(NQL + g, g);
+    if (NA > 0) {      // the stash is read by the wave that wrote it (f32: by another lane of it): order LDS within the wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // tanh of the NQ <= 16 value slots in ONE evaluation: lane lr of every 16-lane row takes row group q = lr (its
+    // value slot sits in lane 0 of the row), the results go back with row broadcasts
+    T yall = 0;
+    if (EPI < 3) {
+        T zsel = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const T v = row16_bcast<0>(acc[q >> 2][0][q & 3]);
+            zsel = lr == q ? v : zsel;
+        }
+        yall = ds_tanh(zsel);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int a = q >> 2, r = q & 3;
+        const int n = n0 + 16 * a + acc_row<T>(lane, r);
+        T z[ST], hv[ST];
+#pragma unroll
+        for (int s = 0; s < ST; ++s) z[s] = acc[a][s][r];
+        if (RESID) {
+            if (q < NQL) {
+                const int rr = 16 * a + acc_row<T>(lane, r);       // row of the wave's block: k-step rr / 4, operand lane group rr % 4
+#pragma unroll
+                for (int s = 0; s < ST; ++s) hv[s] = stash[((rr >> 2) * ST + s) * 64 + ((rr & 3) << 4) + lr];
+            } else {
+                const int slot = (q - NQL) % (DEPTH > 0 ? DEPTH : 1);
+#pragma unroll
+                for (int s = 0; s < ST; ++s) hv[s] = hq[slot][s];
+                if (q + DEPTH < NQ) fetch(q + DEPTH, slot);
+            }
+        }
+        if (EPI >= 3) {
+#pragma unroll
+            for (int s = 0; s < ST; ++s) {
+                T o = ds_tanh(z[s]);
+                if (EPI == 4) o = (hv[s] + o) * rs2;
+                Go[n * P + 16 * s] = o;
+            }
+            continue;
+        }
+        T ss = 0;
+#pragma unroll
+        for (int s = 0; s < ST; ++s)
+            if (16 * s + lr >= 2) ss += z[s] * z[s];
+        ss = row16_sum(ss);
+        const T zL = row16_bcast<1>(z[0]);
+        const T y = row16_bcast_dyn<NQ>(yall, q), d1 = 1 - y * y, d2 = -2 * y * d1;
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            T o = d1 * z[s];
+            if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
+            if (EPI == 2) o = (hv[s] + o) * rs2;
+            __builtin_nontemporal_store(o, &Go[n * P + 16 * s]);      // streamed out: the next reader comes after the whole launch
+        }
+    }
+}
+
 // One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x up to 1024/NB
 // output features (grid.z walks further column blocks); every wave owns 16*NB features.  Tiles 0..n_tiles-1 use (X, W, K);
 // the optional extra tile (blockIdx.x == n_tiles) uses (X2, W2, K2): the shared spin-mean term.
-//   X  : [walker][tile][ldx rows][P]      W : [K][Nout]      Z : [walker][tile (+1)][Nout][P]
+//   X  : [walker][tile][ldx rows][P]      W : [K][Nout]      Z : [walker][tile (+1)][Nout][P]   (EPI 0 / 6 / 7)
+//   layer epilogues (EPI 1 - 4): Z = the next layer's G, [walker][tile][z_tile_stride / P rows][P]
 //   EPI = 0: store the raw products Z.
 //   EPI = 1/2: fused one-electron-layer epilogue (network.py:524-528): z = Z + S + b (the accumulators START at S + b, so
 //              the epilogue has nothing to load for it), tanh chain rule on the jets, (EPI = 2) residual with the layer
@@ -80,7 +165,7 @@ template <typename T, int NB, int ST, int EPI>
 __global__ void __launch_bounds__((NB == 3 || ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1))
 k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride, const T* __restrict__ W, int K,
            const T* __restrict__ X2, size_t x2_walker_stride, const T* __restrict__ W2, int K2, int n_tiles,
-           T* __restrict__ Z, size_t z_walker_stride, int Nout, int P, const T* __restrict__ Sb,
+           T* __restrict__ Z, size_t z_walker_stride, size_t z_tile_stride, int Nout, int P, const T* __restrict__ Sb,
            const T* __restrict__ bias, OrbEpi<T> oe) {
     typedef typename Acc4<T>::type acc_t;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), so
@@ -318,88 +403,223 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
             for (int s = 0; s < ST; ++s) v += acc[a][s][0] + acc[a][s][1] + acc[a][s][2] + acc[a][s][3];
         if (v == T(12345.678)) Z[0] = v;
     } else {
-        // Z here is the next layer's G: [walker][tile][x_tile_stride / P rows][P] (same geometry as X)
-        const T rs2 = T(0.70710678118654752440);
+        // Z here is the next layer's G: [walker][tile][z_tile_stride / P rows][P]; the residual rows are rows n of the input tile
         const T* Gi = X + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
-        T* Go = Z + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
-        // Row groups q = 4a + r (4 rows x P slots each) are independent.  The residual of the first NQL groups comes from
-        // the LDS stash; the others are re-read from memory, up to DEPTH groups in flight, and those loads are issued
-        // before the stash rows are worked on, so their latency overlaps that arithmetic.
-        constexpr int NQ = NB * 4, NQL = NA * 4, NQG = RESID ? NQ - NQL : 0, DMAX = 40 / (ST * (int)sizeof(T) / 4) > 1 ? 40 / (ST * (int)sizeof(T) / 4) : 1,
-                      DEPTH = NQG < DMAX ? NQG : DMAX;      // about 40 VGPRs of loads in flight
-        T hq[DEPTH > 0 ? DEPTH : 1][ST];
-        auto fetch = [&](int q, int slot) {
-            const int n = n0 + 16 * (q >> 2) + acc_row<T>(lane, q & 3);
-#pragma unroll
-            for (int s = 0; s < ST; ++s) hq[slot][s] = Gi[n * P + 16 * s];
-        };
-#pragma unroll
-        for (int g = 0; g < DEPTH; ++g) fetch(NQL + g, g);
-        if (NA > 0) {      // the stash is read by the wave that wrote it (f32: by another lane of it): order LDS within the wave
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // tanh of the NQ <= 16 value slots in ONE evaluation: lane lr of every 16-lane row takes row group q = lr (its
-        // value slot sits in lane 0 of the row), the results go back with row broadcasts
-        T yall = 0;
-        if (EPI < 3) {
-            T zsel = 0;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const T v = row16_bcast<0>(acc[q >> 2][0][q & 3]);
-                zsel = lr == q ? v : zsel;
-            }
-            yall = ds_tanh(zsel);
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int a = q >> 2, r = q & 3;
-            const int n = n0 + 16 * a + acc_row<T>(lane, r);
-            T z[ST], hv[ST];
-#pragma unroll
-            for (int s = 0; s < ST; ++s) z[s] = acc[a][s][r];
-            if (RESID) {
-                if (q < NQL) {
-                    const int rr = 16 * a + acc_row<T>(lane, r);       // row of the wave's block: k-step rr / 4, operand lane group rr % 4
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) hv[s] = stash[((rr >> 2) * ST + s) * 64 + ((rr & 3) << 4) + lr];
-                } else {
-                    const int slot = (q - NQL) % (DEPTH > 0 ? DEPTH : 1);
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) hv[s] = hq[slot][s];
-                    if (q + DEPTH < NQ) fetch(q + DEPTH, slot);
-                }
-            }
-            if (EPI >= 3) {
-#pragma unroll
-                for (int s = 0; s < ST; ++s) {
-                    T o = ds_tanh(z[s]);
-                    if (EPI == 4) o = (hv[s] + o) * rs2;
-                    Go[n * P + 16 * s] = o;
-                }
-                continue;
-            }
-            T ss = 0;
-#pragma unroll
-            for (int s = 0; s < ST; ++s)
-                if (16 * s + lr >= 2) ss += z[s] * z[s];
-            ss = row16_sum(ss);
-            const T zL = row16_bcast<1>(z[0]);
-            const T y = row16_bcast_dyn<NQ>(yall, q), d1 = 1 - y * y, d2 = -2 * y * d1;
-#pragma unroll
-            for (int s = 0; s < ST; ++s) {
-                T o = d1 * z[s];
-                if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
-                if (EPI == 2) o = (hv[s] + o) * rs2;
-                __builtin_nontemporal_store(o, &Go[n * P + 16 * s]);      // streamed out: the next reader comes after the whole launch
-            }
-        }
+        T* Go = Z + (size_t)w * z_walker_stride + (size_t)tile * z_tile_stride + lr;
+        layer_epilogue<T, NB, ST, EPI, NA>(acc, Gi, Go, stash, n0, lane, P);
     }
     stamp();
     if (EPI == 2 && oe.clk && wave == 0 && lane == 0) {
         atomicAdd(oe.clk, (unsigned long long)(clock64() - clk_c0));
         atomicAdd(oe.clk + 1, (unsigned long long)(wall_clock64() - clk_r0));
     }
+}
+
+// =====================================================================================
+// First hidden layer on the LOW-RANK form of its input.
+//
+// The output of layer 0 has, in its derivative slots, rank K0 = (rows of the layer-0 input, per-electron + shared):
+//     G1[n][s] = y'_n * sum_{k < K0} W0[k][n] X0[k][s]            (s >= 2),     G1[n][0] = y_n,   G1[n][1] = oL_n
+// (network.py:524-528 with the tanh chain rule on the jets; no residual at layer 0 when its width changes), so the product of
+// layer 1 over its Kh one-electron rows collapses to K0 + 2 rows with PER-ELECTRON weights
+//     C[m][k] = sum_n W1[n][m] y'_n W0[k][n]   (k < K0),    C[m][K0] = sum_n W1[n][m] y_n,    C[m][K0 + 1] = sum_n W1[n][m] oL_n
+//     Z[m][s] = sum_{k < K0} C[m][k] X0[k][s]  (s >= 2),    Z[m][0] = C[m][K0],               Z[m][1] = C[m][K0 + 1]
+// plus the pair-mean rows (dense, as before) and the shared term S.  Per wave tile of 16 NB features x 16 ST slots:
+//     phase 1   C = W1_h^T B1, B1[n][c] = (y'_n W0T[n][c] | y_n | oL_n): Kh / 4 k-steps of NB x NC MFMAs (NC = column tiles of c)
+//     phase 2   Z = C X0' (A operand from the wave's LDS copy of C; X0' = X0 with its value / Laplacian slots zeroed, plus the two
+//               unit rows that route C[:, K0], C[:, K0 + 1] to slots 0 / 1) + W1_m^T M2: (K0 + 4 + Km2) / 4 k-steps of NB x ST
+// instead of (Kh + Km2) / 4 k-steps of NB x ST: at 24 electrons 952 MFMAs per wave tile instead of 1600.  The epilogue is the one of
+// k_jet_gemm (EPI 1 / 2); the residual rows are read from G1.
+// =====================================================================================
+template <typename T> struct LrArgs {
+    const T* XL; size_t xl_ws, xl_ts;    // layer-0 per-electron input rows [walker][tile][K0loc][P]
+    const T* M0; size_t m0_ws;           // layer-0 shared input rows (spin means of the input features) [walker][K0sh][P]
+    int K0loc, K0sh;                     // multiples of 4
+    const T* W0T;                        // [Kh][16 NC]: W0T[n][c] = layer-0 weight of input row c (per-electron rows, then shared rows), 0 beyond
+    const T* G1; size_t g_ws, g_ts;      // layer-1 input tiles [walker][tile][rows][P]: slots 0 / 1 of rows < Kh = y, oL; rows Kh.. = pair means
+    const T* W1; int Kh, Km2;            // layer-1 weights [Kh + Km2][Nout]
+    T* Gout; size_t go_ws, go_ts;        // layer-1 output tiles
+    const T* S1;                         // [walker][Nout][P] shared term of layer 1 (with its bias)
+    int Nout, P, n_tiles;
+};
+template <int NB, int NC> constexpr int lr_ncp() { return 16 * NC + 1; }
+template <typename T, int NB, int NC> inline size_t lr_lds_bytes(unsigned threads, int Kh) {
+    return ((size_t)2 * Kh + (size_t)(threads / 64) * 16 * NB * lr_ncp<NB, NC>()) * sizeof(T);
+}
+
+template <typename T, int NB, int ST, int NC, bool RES>
+__global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)) k_layer1_lr(LrArgs<T> A) {
+    typedef typename Acc4<T>::type acc_t;
+    constexpr int NCP = lr_ncp<NB, NC>();
+    // (placement as in k_jet_gemm: the tiles of one walker on one XCD, column blocks of a tile side by side)
+    int tile = blockIdx.x, w = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, q = b >> 3;
+        w = (q / gridDim.x) * 8 + (b & 7);
+        tile = q % gridDim.x;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int zb = 0;
+    if (gridDim.x > (unsigned)A.n_tiles) {
+        const int gzf = gridDim.x / A.n_tiles;
+        zb = tile % gzf;
+        tile /= gzf;
+    }
+    const int lr = lane & 15, lq = lane >> 4, n0 = (zb * (blockDim.x >> 6) + wave) * 16 * NB;
+    const int P = A.P, Nout = A.Nout, Kh = A.Kh, K0 = A.K0loc + A.K0sh;
+    extern __shared__ __attribute__((aligned(16))) char lr_smem[];
+    T* yl = reinterpret_cast<T*>(lr_smem);                              // [Kh][2] = (y_n, oL_n) of this electron
+    T* Cl = yl + 2 * Kh + (size_t)wave * (16 * NB * NCP);               // the wave's C block [16 NB][NCP]
+    const T* G1t = A.G1 + (size_t)w * A.g_ws + (size_t)tile * A.g_ts;
+    {
+        typedef T vec2 __attribute__((ext_vector_type(2)));
+        for (int n = threadIdx.x; n < Kh; n += blockDim.x)
+            *reinterpret_cast<vec2*>(yl + 2 * n) = *reinterpret_cast<const vec2*>(G1t + (size_t)n * P);      // slots 0, 1 (rows are 128-byte aligned)
+    }
+    __syncthreads();
+    if (n0 >= Nout) return;
+    // ---------------- phase 1: C[m][c] = sum_n W1[n][m] B1[n][c]
+    acc_t c1[NB][NC];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int s = 0; s < NC; ++s) c1[a][s] = acc_t{0, 0, 0, 0};
+    {
+        T av[4][NB], wv[4][NC];
+        const T* Wl = A.W1 + n0 + (size_t)lq * Nout + lr;
+        const T* Tl = A.W0T + lq * (16 * NC) + lr;
+        auto load_set = [&](int u) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) av[u][a] = Wl[16 * a];
+#pragma unroll
+            for (int s = 0; s < NC; ++s) wv[u][s] = Tl[16 * s];
+            Wl += (size_t)4 * Nout;
+            Tl += 4 * 16 * NC;
+        };
+        auto step = [&](int u, int ks) {
+            typedef T vec2 __attribute__((ext_vector_type(2)));
+            const vec2 yo = *reinterpret_cast<const vec2*>(yl + 2 * (4 * ks + lq));
+            const T y = yo[0], d1 = 1 - y * y;
+            T bv[NC];
+#pragma unroll
+            for (int s = 0; s < NC; ++s) {
+                const int c = 16 * s + lr;
+                bv[s] = c == K0 ? y : (c == K0 + 1 ? yo[1] : d1 * wv[u][s]);
+            }
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int s = 0; s < NC; ++s) c1[a][s] = mfma16(av[u][a], bv[s], c1[a][s]);
+        };
+        const int nks = Kh / 4;                       // (Kh is a multiple of 16: launcher)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_set(u);
+        int ks = 0;
+        for (; ks + 4 < nks; ks += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { step(u, ks + u); load_set(u); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) step(u, ks + u);
+    }
+    // the accumulator layout (row = feature, lane = column c) is not the A-operand layout (lane = feature, k = c): through LDS
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int s = 0; s < NC; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cl[(16 * a + acc_row<T>(lane, r)) * NCP + 16 * s + lr] = c1[a][s][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- phase 2
+    acc_t acc[NB][ST];
+    {
+        const T* Sp0 = A.S1 + (size_t)w * Nout * P + lr;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * a + acc_row<T>(lane, r);
+#pragma unroll
+                for (int s = 0; s < ST; ++s) acc[a][s][r] = Sp0[n * P + 16 * s];
+            }
+    }
+    {
+        // pair-mean rows: dense, operands from memory through the ring of k_jet_gemm
+        constexpr int NSET = ring_sets<T, NB, ST>();
+        T av[NSET][NB], bv[NSET][ST];
+        const T* Wl = A.W1 + (size_t)(Kh + lq) * Nout + n0 + lr;
+        const T* Xl = G1t + (size_t)(Kh + lq) * P + lr;
+        auto load_set = [&](int u) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a) av[u][a] = Wl[16 * a];
+#pragma unroll
+            for (int s = 0; s < ST; ++s) bv[u][s] = Xl[16 * s];
+            Wl += (size_t)4 * Nout;
+            Xl += (size_t)4 * P;
+        };
+        auto step = [&](int u) {
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
+        };
+        const int nks = A.Km2 / 4;                    // a multiple of NSET... not required: the tail reloads conditionally
+#pragma unroll
+        for (int u = 0; u < NSET; ++u)
+            if (u < nks) load_set(u);
+        int ks = 0;
+        for (; ks + 2 * NSET <= nks; ks += NSET) {
+#pragma unroll
+            for (int u = 0; u < NSET; ++u) { step(u); load_set(u); }
+        }
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) {
+            if (ks + u < nks) step(u);
+            if (ks + u + NSET < nks) load_set(u);
+        }
+        ks += NSET;
+#pragma unroll
+        for (int u = 0; u < NSET; ++u)
+            if (ks + u < nks) step(u);
+    }
+    {
+        // the K0 low-rank rows: A operand = the wave's C block, B operand = the layer-0 input rows without their slots 0 / 1
+        const T* Xl = A.XL + (size_t)w * A.xl_ws + (size_t)tile * A.xl_ts + (size_t)lq * P + lr;
+        const T* Ml = A.M0 + (size_t)w * A.m0_ws + (size_t)lq * P + lr;
+        const T* Ca = Cl + lr * NCP + lq;
+        auto rows = [&](const T* Xp, int nk, int c0) {
+            for (int ks = 0; ks < nk; ++ks) {
+                T av[NB], bv[ST];
+#pragma unroll
+                for (int s = 0; s < ST; ++s) bv[s] = Xp[(size_t)(4 * ks) * P + 16 * s];
+                bv[0] = lr < 2 ? T(0) : bv[0];
+#pragma unroll
+                for (int a = 0; a < NB; ++a) av[a] = Ca[16 * a * NCP + c0 + 4 * ks];
+#pragma unroll
+                for (int a = 0; a < NB; ++a)
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[a], bv[s], acc[a][s]);
+            }
+        };
+        rows(Xl, A.K0loc / 4, 0);
+        rows(Ml, A.K0sh / 4, A.K0loc);
+        // columns K0, K0 + 1 of C go to slots 0, 1: one k-step on slot tile 0 with unit rows (lane groups 2, 3 contribute zeros)
+        const T one = (lq == 0 && lr == 0) || (lq == 1 && lr == 1) ? T(1) : T(0);
+#pragma unroll
+        for (int a = 0; a < NB; ++a) acc[a][0] = mfma16(Ca[16 * a * NCP + K0], one, acc[a][0]);
+    }
+    T* Got = A.Gout + (size_t)w * A.go_ws + (size_t)tile * A.go_ts + lr;
+    layer_epilogue<T, NB, ST, (RES ? 2 : 1), 0>(acc, G1t + lr, Got, (const T*)nullptr, n0, lane, P);
+}
+
+// W0T[n][c] (c < NCW): the layer-0 weight of input row c for output feature n -- per-electron rows, then the shared rows, zero beyond
+template <typename T>
+__global__ void k_lr_w0t(const T* __restrict__ Wloc0, const T* __restrict__ Wsh0, int K0loc, int K0sh, int Kh, int NCW, T* __restrict__ W0T) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Kh * NCW) return;
+    const int n = idx / NCW, c = idx - n * NCW;
+    W0T[idx] = c < K0loc ? Wloc0[(size_t)c * Kh + n] : (c < K0loc + K0sh ? Wsh0[(size_t)(c - K0loc) * Kh + n] : T(0));
 }
 
 // Shared spin-mean term of a hidden layer, S[n][slot] = sum_sp sum_k W_sh[sp*Kh + k][n] * mean_{i in sp} G[i][k][slot]

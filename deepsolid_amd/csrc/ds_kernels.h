@@ -63,8 +63,9 @@ __device__ __forceinline__ int spin_of(int i, int n_up) { return i < n_up ? 0 : 
 template <typename T>
 __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restrict__ x, const T* __restrict__ env_pi0,
                                                   const T* __restrict__ env_sg0, const T* __restrict__ env_pi1,
-                                                  const T* __restrict__ env_sg1, T* __restrict__ G, T* __restrict__ MEAN,
+                                                  const T* __restrict__ env_sg1, T* __restrict__ G, int ldg, T* __restrict__ MEAN,
                                                   T* __restrict__ H2, T* __restrict__ Q) {
+    // ldg = rows per electron tile of G (S.ldk, or the layer-0 input width when the tiles go to their own buffer)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);        // [N][3] raw
     T* px = xs + 3 * S.N;                          // [N][3] wrapped into the primitive cell
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
     __syncthreads();
     const int K1 = S.h1[0];      // nf * A rounded up to a multiple of 4 (zero rows pad)
     // one-electron stream rows of G: row k = nf*a + f = [sd, rel...] per atom (network.py:503-504)
-    T* Gw = G + (size_t)w * N * S.ldk * P;
+    T* Gw = G + (size_t)w * N * ldg * P;
     for (int idx = tid; idx < N * K1 * P; idx += nt) {
         const int slot = idx % P, k = (idx / P) % K1, i = idx / (P * K1);
         T v = 0;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
             else if (slot == 1) v = j.l;
             else if (slot < S.D && (slot - 2) / 3 == i) v = j.g[(slot - 2) % 3];
         }
-        Gw[((size_t)i * S.ldk + k) * P + slot] = v;
+        Gw[((size_t)i * ldg + k) * P + slot] = v;
     }
     // spin means of the one-electron stream
     T* Mw = MEAN + (size_t)w * S.nch * K1 * P;
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
 // =====================================================================================
 // grid.z splits the K2 pair features (the pair jets of a split then fit several workgroups' worth of LDS per CU)
 template <typename T>
-__global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restrict__ H2, int K2, T* __restrict__ G, int row0) {
+__global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restrict__ H2, int K2, T* __restrict__ G, int row0, int ldg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int e = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
     const int N = S.N, P = S.P, NP = S.NP;
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
     }
     __syncthreads();
     // h2[j][e] depends on r = x_j - x_e: d/dx_j = +d/dr, d/dx_e = -d/dr
-    T* Ge = G + ((size_t)(w * N + e) * S.ldk + row0 + k0) * P;
+    T* Ge = G + ((size_t)(w * N + e) * ldg + row0 + k0) * P;
     // a thread produces four consecutive slots of one row (32-byte store; one division per four elements)
     typedef T vec4 __attribute__((ext_vector_type(4)));
     const int QP = P / 4;
