@@ -50,6 +50,7 @@ struct WsLayout {
     size_t G, MEAN, ZB, H2, Q, MOUT, MINV, DETS, TR;      // sizes of one buffer per walker
     size_t PARTM = 0;                                      // value chain: per-tile segment sums of the pair layer (k_two_layer)
     size_t XL = 0;                                         // layer-0 input tiles [N][h1[0] + nch h2[0]][P] (low-rank first hidden layer)
+    size_t YO = 0;                                         // (y, oL) of the layer-0 output per electron and feature [N][h1[1]][2]
     size_t mout_off[2], minv_off[2], dets_off[2], tr_off[2];
     size_t per_walker;                                     // total elements per walker
 };
@@ -78,6 +79,7 @@ struct ds_system {
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
+    bool lr_keep_g1 = false;          // DS_LR_KEEP_G1: layer 0 still writes its dense output (the low-rank layer reads y, oL and the residual from it)
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
     int dbg = 0;                      // DS_DBG (kernel development): 32 = phase stamps of one wave; 1 / 2 switch arithmetic off in a `make EXP=1` build only
@@ -269,7 +271,7 @@ void build_layouts(ds_system* s) {
     for (int l = 0; l <= S.n_layers; ++l) { h1max = std::max(h1max, S.h1[l]); h2max = std::max(h2max, S.h2[l]); }
     w.G = (size_t)S.N * S.ldk * S.P;
     w.MEAN = (size_t)S.nch * h1max * S.P;
-    w.ZB = (size_t)std::max(h1max, std::max(S.ocols[0], S.ocols[1])) * S.P;   // shared spin-mean term S of one layer / orbital head
+    w.ZB = (size_t)std::max(2 * h1max, std::max(S.ocols[0], S.ocols[1])) * S.P;   // shared spin-mean term S of one layer (of two: the low-rank layer 1 needs S of layer 0 too) / orbital head
     for (int c = 0; c < S.nch; ++c)                  // ... or the orbital GEMM output of one spin
         w.ZB = std::max(w.ZB, (size_t)(c == 0 ? S.n_up : S.n_dn) * S.ocols[c] * S.P);
     w.H2 = (size_t)h2max * 5 * S.NP;
@@ -285,7 +287,8 @@ void build_layouts(ds_system* s) {
     }
     w.MOUT = mo; w.MINV = rup((int)mi, 16); w.DETS = rup((int)de, 16); w.TR = tr;
     w.XL = (size_t)S.N * (S.h1[0] + S.nch * S.h2[0]) * S.P;
-    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR + w.XL;
+    w.YO = (size_t)rup(S.N * S.h1[1] * 2, 16);
+    w.per_walker = 2 * w.G + 2 * w.MEAN + w.ZB + 2 * w.H2 + w.Q + w.MOUT + w.MINV + w.DETS + w.TR + w.XL + w.YO;
     // value chain: the slot axis carries PV walkers (ds_value.h)
     WsLayout& v = s->wsv;
     const size_t PV = ds::PV;
@@ -309,7 +312,7 @@ void build_layouts(ds_system* s) {
 }
 
 template <typename T> struct Carve {
-    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR, *XL;
+    T *G[2], *MEAN[2], *ZB, *H2[2], *Q, *MOUT, *MINV, *DETS, *TR, *XL, *YO;
 };
 template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     const WsLayout& w = s->ws;
@@ -325,6 +328,7 @@ template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
     c.DETS = p; p += w.DETS * Bc;
     c.TR = p; p += w.TR * Bc;
     c.XL = p; p += w.XL * Bc;
+    c.YO = p; p += w.YO * Bc;
     return c;
 }
 
@@ -396,6 +400,9 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     const int lr_nc = std::max(2, (K0loc + K0sh + 4 + 15) / 16);      // column tiles of the per-electron weights C (instances: 2, 3, 4)
     const bool lr_on = s->use_lr && !dr && S.n_layers >= 2 && lr_nc <= 4 && S.h1[1] % 16 == 0 && (S.nch * S.h2[1]) % 4 == 0 &&
                        3 * (K0loc + K0sh + 4) <= S.h1[1];
+    // ... and the dense layer-0 output is not written at all: k_layer0_stats leaves (y, oL) per electron and the spin means of
+    // the output (the input of layer 1's shared term); layer 1 recomputes its residual rows from the layer-0 input.
+    const bool lr_nog1 = lr_on && !s->lr_keep_g1;
     // 1. features
     {
         ProfScope ps(s, DS_PROF_FEATURES, st);
@@ -447,6 +454,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             dim3 block; unsigned gz;
             gemm_geom(Nout, NB, &block, &gz, ST);
             const size_t gws = (size_t)S.N * S.ldk * S.P, gts = (size_t)S.ldk * S.P;
+            T* Sl = (lr_nog1 && l == 1) ? c.ZB + (size_t)Bc * S.h1[1] * S.P : c.ZB;      // this layer's shared term
             {
                 // shared spin-mean term S (one tile per walker): layer 0 from the MEAN buffer of k_features,
                 // hidden layers straight from the electron rows of G (means formed on the fly)
@@ -455,12 +463,17 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                     hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
                                        (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[0], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
                                        c.ZB, (size_t)Nout * S.P, (size_t)0, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                else if (lr_nog1 && l == 1)
+                    // the spin means of the layer-0 output came out of k_layer0_stats (MEAN[1]); S of layer 0 stays in front of this one
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
+                                       (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[1], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
+                                       Sl, (size_t)Nout * S.P, (size_t)0, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
                 else {
                     // (its own geometry: as many waves per workgroup as possible, every workgroup re-forms the spin means)
                     dim3 sblock; unsigned sgz;
                     gemm_geom(Nout, NB, &sblock, &sgz);
                     hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, sgz), sblock, 2 * 16 * S.P * sizeof(T), st, S,
-                                       c.G[gi], blk(s->i_wsh[l]), Kh, c.ZB, Nout, S.P, blk(s->i_b[l]), 0);
+                                       c.G[gi], blk(s->i_wsh[l]), Kh, Sl, Nout, S.P, blk(s->i_b[l]), 0);
                 }
             }
             {
@@ -472,14 +485,36 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             if (lr_on && l == 1) {
                 // first hidden layer on the low-rank form of the layer-0 output (ds_gemm.h: k_layer1_lr)
                 ds::LrArgs<T> la{c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, c.MEAN[0], (size_t)K0sh * S.P, K0loc, K0sh,
-                                 (const T*)s->lr_w0t, c.G[gi], gws, gts, blk(s->i_wloc[l]), Kh, S.nch * K2, c.G[gi ^ 1], gws, gts, c.ZB,
-                                 Nout, S.P, S.N};
+                                 (const T*)s->lr_w0t, c.G[gi], gws, gts, blk(s->i_wloc[l]), Kh, S.nch * K2, c.G[gi ^ 1], gws, gts, Sl,
+                                 Nout, S.P, S.N, c.YO, L.YO, blk(s->i_wloc[0]), c.ZB};
                 const dim3 lgrid(S.N * gz, (unsigned)Bc, 1);
-#define DS_LR(NCV, RESV) hipLaunchKernelGGL((ds::k_layer1_lr<T, NB, ST, NCV, RESV>), lgrid, block, (ds::lr_lds_bytes<T, NB, NCV>(block.x, Kh)), st, la)
-                if (lr_nc <= 2) { if (res) DS_LR(2, true); else DS_LR(2, false); }
-                else if (lr_nc == 3) { if (res) DS_LR(3, true); else DS_LR(3, false); }
-                else { if (res) DS_LR(4, true); else DS_LR(4, false); }
+#define DS_LR(NCV, RESV, NOG) hipLaunchKernelGGL((ds::k_layer1_lr<T, NB, ST, NCV, RESV, NOG>), lgrid, block, (ds::lr_lds_bytes<T, NB, NCV>(block.x, Kh)), st, la)
+#define DS_LR2(NCV) do { if (lr_nog1) { if (res) DS_LR(NCV, true, true); else DS_LR(NCV, false, true); } else { if (res) DS_LR(NCV, true, false); else DS_LR(NCV, false, false); } } while (0)
+                if (lr_nc <= 2) DS_LR2(2); else if (lr_nc == 3) DS_LR2(3); else DS_LR2(4);
+#undef DS_LR2
 #undef DS_LR
+            } else if (lr_nog1 && l == 0) {
+                // layer 0 without its dense output: (y, oL) per electron + the spin means of the output (ds_gemm.h)
+                const int nks0 = K0loc / 4;
+                bool one_kernel = false;
+                if constexpr (ST <= 5) {
+                    // one kernel when a wave holds all slot tiles of 16 features (k_layer0_stats)
+                    const dim3 sgrid(S.nch * (unsigned)((Nout + 63) / 64), (unsigned)Bc);
+#define DS_L0S(NKSV) hipLaunchKernelGGL((ds::k_layer0_stats<T, ST, NKSV>), sgrid, dim3(256), 0, st, S, c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, \
+                                        blk(s->i_wloc[0]), c.ZB, Nout, S.P, c.YO, c.MEAN[1])
+                    one_kernel = nks0 >= 2 && nks0 <= 4;
+                    if (nks0 == 2) DS_L0S(2); else if (nks0 == 3) DS_L0S(3); else if (nks0 == 4) DS_L0S(4);
+#undef DS_L0S
+                }
+                if (!one_kernel) {
+                    // (y, oL) from the layer kernel with the output dropped (EPI 9), then the means per slot chunk (k_layer0_means)
+                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 9>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, Xin, xws, xts,
+                                       blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.YO, L.YO, (size_t)2 * Nout, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                    constexpr int STC = 5;
+                    const unsigned nfb = (unsigned)((Nout + 63) / 64), nck = (unsigned)((S.P / 16 + STC - 1) / STC);
+                    hipLaunchKernelGGL((ds::k_layer0_means<T, STC>), dim3(S.nch * nfb * nck, (unsigned)Bc), dim3(256), 0, st, S, c.XL,
+                                       (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, blk(s->i_wloc[0]), K0loc, c.ZB, Nout, S.P, c.YO, c.MEAN[1]);
+                }
             } else if (res) {
                 ds::OrbEpi<T> oe_clk{};
                 oe_clk.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
@@ -1348,6 +1383,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
+    s->lr_keep_g1 = getenv("DS_LR_KEEP_G1") != nullptr;
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     // (grid.y carries the walker index: at most 65535 walkers per launch)
     if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::min<int64_t>(65535, std::max<int64_t>(1, atol(e)));

@@ -8,6 +8,8 @@
 // The GEMM main loop needs only its accumulators and two k-steps of operands in registers, which
 // keeps two waves per SIMD resident: one wave's loads / epilogue hide behind the other's MFMAs.
 #pragma once
+#include <type_traits>
+
 #include "ds_kernels.h"
 
 namespace ds {
@@ -66,16 +68,20 @@ __host__ __device__ constexpr bool gemm_uses_ring(int epi) { return epi == 0 || 
 // slots 16 s + lr.  EPI 1 / 2: tanh chain rule on the jets without / with the residual; EPI 3 / 4: plain tanh (value chain).
 //   Gi: residual rows of the tile (+ lr), row stride P;  Go: output tile (+ lr), row stride P;  stash: the wave's LDS copy of the
 //   first NA 16-row blocks of its residual rows (stash_blocks), the others are re-read from Gi.
-template <typename T, int NB, int ST, int EPI, int NA>
+//   rf: optional residual + store stage instead of Gi / stash / Go: the epilogue leaves the pre-residual output of 16-row block a
+//   in acc[a] and calls rf(a), which adds the residual rows and stores (k_layer1_lr recomputes those rows block by block)
+struct NoResidFn {};
+template <typename T, int NB, int ST, int EPI, int NA, typename RF = NoResidFn>
 __device__ __forceinline__ void layer_epilogue(typename Acc4<T>::type (&acc)[NB][ST], const T* __restrict__ Gi, T* __restrict__ Go,
-                                               const T* stash, int n0, int lane, int P) {
+                                               const T* stash, int n0, int lane, int P, RF&& rf = RF()) {
     constexpr bool RESID = EPI == 2 || EPI == 4;
+    constexpr bool CUSTOM = !std::is_same<typename std::decay<RF>::type, NoResidFn>::value;
     const int lr = lane & 15;
     const T rs2 = T(0.70710678118654752440);
     // Row groups q = 4a + r (4 rows x P slots each) are independent.  The residual of the first NQL groups comes from
     // the LDS stash; the others are re-read from memory, up to DEPTH groups in flight, and those loads are issued
     // before the stash rows are worked on, so their latency overlaps that arithmetic.
-    constexpr int NQ = NB * 4, NQL = NA * 4, NQG = RESID ? NQ - NQL : 0, DMAX = 40 / (ST * (int)sizeof(T) / 4) > 1 ? 40 / (ST * (int)sizeof(T) / 4) : 1,
+    constexpr int NQ = NB * 4, NQL = NA * 4, NQG = (RESID && !CUSTOM) ? NQ - NQL : 0, DMAX = 40 / (ST * (int)sizeof(T) / 4) > 1 ? 40 / (ST * (int)sizeof(T) / 4) : 1,
                   DEPTH = NQG < DMAX ? NQG : DMAX;      // about 40 VGPRs of loads in flight
     T hq[DEPTH > 0 ? DEPTH : 1][ST];
     auto fetch = [&](int q, int slot) {
@@ -92,7 +98,7 @@ __device__ __forceinline__ void layer_epilogue(typename Acc4<T>::type (&acc)[NB]
     // tanh of the NQ <= 16 value slots in ONE evaluation: lane lr of every 16-lane row takes row group q = lr (its
     // value slot sits in lane 0 of the row), the results go back with row broadcasts
     T yall = 0;
-    if (EPI < 3) {
+    if (EPI < 3 || EPI == 9) {
         T zsel = 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -109,7 +115,8 @@ __device__ __forceinline__ void layer_epilogue(typename Acc4<T>::type (&acc)[NB]
 #pragma unroll
         for (int s = 0; s < ST; ++s) z[s] = acc[a][s][r];
         if (RESID) {
-            if (q < NQL) {
+            if constexpr (CUSTOM) {
+            } else if (q < NQL) {
                 const int rr = 16 * a + acc_row<T>(lane, r);       // row of the wave's block: k-step rr / 4, operand lane group rr % 4
 #pragma unroll
                 for (int s = 0; s < ST; ++s) hv[s] = stash[((rr >> 2) * ST + s) * 64 + ((rr & 3) << 4) + lr];
@@ -120,7 +127,7 @@ __device__ __forceinline__ void layer_epilogue(typename Acc4<T>::type (&acc)[NB]
                 if (q + DEPTH < NQ) fetch(q + DEPTH, slot);
             }
         }
-        if (EPI >= 3) {
+        if (EPI == 3 || EPI == 4) {
 #pragma unroll
             for (int s = 0; s < ST; ++s) {
                 T o = ds_tanh(z[s]);
@@ -140,9 +147,12 @@ __device__ __forceinline__ void layer_epilogue(typename Acc4<T>::type (&acc)[NB]
         for (int s = 0; s < ST; ++s) {
             T o = d1 * z[s];
             if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
+            if (EPI == 9) { if (s == 0 && lr < 2) Go[2 * n] = o; continue; }      // (Go carries + lr: slot 0 -> y, slot 1 -> oL)
+            if (CUSTOM && RESID) { acc[a][s][r] = o; continue; }
             if (EPI == 2) o = (hv[s] + o) * rs2;
             __builtin_nontemporal_store(o, &Go[n * P + 16 * s]);      // streamed out: the next reader comes after the whole launch
         }
+        if constexpr (CUSTOM && RESID) { if (r == 3) rf(a); }
     }
 }
 
@@ -156,6 +166,8 @@ __device__ __forceinline__ void layer_epilogue(typename Acc4<T>::type (&acc)[NB]
 //              the epilogue has nothing to load for it), tanh chain rule on the jets, (EPI = 2) residual with the layer
 //              input rows (parked in LDS during the main loop, see stash_blocks), store into the next layer's G.
 //              S : [walker][Nout][P] shared spin-mean term, Gout : [walker][tile][ldo rows][P].
+//   EPI = 9: layer epilogue that keeps only (y_n, oL_n) = slots 0 / 1 of its output: Z = YO [walker][tile][Nout][2] (the dense
+//            output is not needed: low-rank first hidden layer, k_layer1_lr / k_layer0_means)
 //   EPI = 3/4: value chain (slots = walkers): plain tanh(Z + S + b) without / with residual.
 //   EPI = 5: orbital head (network.py:543-557): complex phi from packed columns, M = phi * q (envelope x Bloch
 //            phase 5-jet of the tile's electron) with the product rule, stored into MOUT.
@@ -181,7 +193,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // (wave-uniform values in SGPRs)
     // (layer launches fold the column blocks into grid.x: the workgroups sharing an electron tile then run side by side on one XCD)
     int zb = blockIdx.z;
-    if ((EPI == 1 || EPI == 2 || EPI == 5) && gridDim.x > (unsigned)n_tiles) {
+    if ((EPI == 1 || EPI == 2 || EPI == 5 || EPI == 9) && gridDim.x > (unsigned)n_tiles) {
         const int gzf = gridDim.x / n_tiles;
         zb = tile % gzf;
         tile /= gzf;
@@ -209,7 +221,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     // Xp / Wp stay wave-uniform (SGPR pairs advanced by scalar adds); the lane's place in the operand tile is a 32-bit offset
     Wp += n0;
     const unsigned xo = lq * P + lr, wo = lq * Nout + lr;
-    constexpr bool LAYER = EPI >= 1 && EPI <= 4, RESID = EPI == 2 || EPI == 4;
+    constexpr bool LAYER = (EPI >= 1 && EPI <= 4) || EPI == 9, RESID = EPI == 2 || EPI == 4;
     constexpr int NA = RESID ? stash_blocks<T, NB, ST>() : 0;          // 16-row blocks of the residual parked in LDS
     extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
     T* stash = reinterpret_cast<T*>(gemm_smem) + (size_t)wave * (NA * 4 * ST * 64);
@@ -441,13 +453,16 @@ template <typename T> struct LrArgs {
     T* Gout; size_t go_ws, go_ts;        // layer-1 output tiles
     const T* S1;                         // [walker][Nout][P] shared term of layer 1 (with its bias)
     int Nout, P, n_tiles;
+    // layer-0 output never written (NOG1): y, oL come from YO, the residual rows are recomputed from the layer-0 input
+    const T* YO; size_t yo_ws;           // [walker][tile][Kh][2] = (y_n, oL_n)  (k_layer0_stats)
+    const T* W0; const T* S0;            // layer-0 per-electron weights [K0loc][Kh], its shared term [walker][Kh][P]
 };
 template <int NB, int NC> constexpr int lr_ncp() { return 16 * NC + 1; }
 template <typename T, int NB, int NC> inline size_t lr_lds_bytes(unsigned threads, int Kh) {
     return ((size_t)2 * Kh + (size_t)(threads / 64) * 16 * NB * lr_ncp<NB, NC>()) * sizeof(T);
 }
 
-template <typename T, int NB, int ST, int NC, bool RES>
+template <typename T, int NB, int ST, int NC, bool RES, bool NOG1>
 __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)) k_layer1_lr(LrArgs<T> A) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int NCP = lr_ncp<NB, NC>();
@@ -473,8 +488,10 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
     const T* G1t = A.G1 + (size_t)w * A.g_ws + (size_t)tile * A.g_ts;
     {
         typedef T vec2 __attribute__((ext_vector_type(2)));
+        const T* yo = A.YO + (size_t)w * A.yo_ws + (size_t)tile * 2 * Kh;
         for (int n = threadIdx.x; n < Kh; n += blockDim.x)
-            *reinterpret_cast<vec2*>(yl + 2 * n) = *reinterpret_cast<const vec2*>(G1t + (size_t)n * P);      // slots 0, 1 (rows are 128-byte aligned)
+            *reinterpret_cast<vec2*>(yl + 2 * n) = NOG1 ? *reinterpret_cast<const vec2*>(yo + 2 * n)
+                                                        : *reinterpret_cast<const vec2*>(G1t + (size_t)n * P);      // slots 0, 1 (rows are 128-byte aligned)
     }
     __syncthreads();
     if (n0 >= Nout) return;
@@ -544,73 +561,264 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
                 for (int s = 0; s < ST; ++s) acc[a][s][r] = Sp0[n * P + 16 * s];
             }
     }
+    const T* Ca = Cl + lr * NCP + lq;
     {
-        // pair-mean rows: dense, operands from memory through the ring of k_jet_gemm
+        // One operand ring over the pair-mean rows (dense: A = W1 rows Kh.., B = rows Kh.. of the input tile) and then the K0
+        // low-rank rows (A = the wave's C block in LDS, B = the layer-0 input rows without their slots 0 / 1): the B rows of the
+        // low-rank k-steps are requested three k-steps ahead like all others.  Branch-free: the (unused) A load of a low-rank k-step
+        // re-reads the last pair-mean row, the pointers are selected by the k-step index.
         constexpr int NSET = ring_sets<T, NB, ST>();
         T av[NSET][NB], bv[NSET][ST];
-        const T* Wl = A.W1 + (size_t)(Kh + lq) * Nout + n0 + lr;
-        const T* Xl = G1t + (size_t)(Kh + lq) * P + lr;
+        const int nm2 = A.Km2 / 4, nl = A.K0loc / 4, nk = nm2 + K0 / 4;
+        const T* Wm = A.W1 + (size_t)(Kh + lq) * Nout + n0 + lr;
+        const T* Xm = G1t + (size_t)(Kh + lq) * P + lr;
+        const T* Xl = A.XL + (size_t)w * A.xl_ws + (size_t)tile * A.xl_ts + (size_t)lq * P + lr;
+        const T* Ml = A.M0 + (size_t)w * A.m0_ws + (size_t)lq * P + lr;
+        int kl = 0;                                        // next k-step to request
         auto load_set = [&](int u) {
+            const int km = kl < nm2 ? kl : nm2 - 1;
+            const T* wp = Wm + (size_t)(4 * km) * Nout;
+            const T* xp = kl < nm2 ? Xm + (size_t)(4 * kl) * P : (kl - nm2 < nl ? Xl + (size_t)(4 * (kl - nm2)) * P : Ml + (size_t)(4 * (kl - nm2 - nl)) * P);
 #pragma unroll
-            for (int a = 0; a < NB; ++a) av[u][a] = Wl[16 * a];
+            for (int a = 0; a < NB; ++a) av[u][a] = wp[16 * a];
 #pragma unroll
-            for (int s = 0; s < ST; ++s) bv[u][s] = Xl[16 * s];
-            Wl += (size_t)4 * Nout;
-            Xl += (size_t)4 * P;
+            for (int s = 0; s < ST; ++s) bv[u][s] = xp[16 * s];
+            ++kl;
         };
-        auto step = [&](int u) {
+        auto step = [&](int u, int k) {
+            const bool low = k >= nm2;
+            const int c = low ? 4 * (k - nm2) : 0;
+            T b0 = bv[u][0];
+            b0 = (low && lr < 2) ? T(0) : b0;
 #pragma unroll
-            for (int a = 0; a < NB; ++a)
+            for (int a = 0; a < NB; ++a) {
+                const T cl = Ca[16 * a * NCP + c];
+                const T aa = low ? cl : av[u][a];
 #pragma unroll
-                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
+                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(aa, s == 0 ? b0 : bv[u][s], acc[a][s]);
+            }
         };
-        const int nks = A.Km2 / 4;                    // a multiple of NSET... not required: the tail reloads conditionally
+        // (nk >= NSET: at least one pair-mean k-step and K0 >= 8)
 #pragma unroll
-        for (int u = 0; u < NSET; ++u)
-            if (u < nks) load_set(u);
+        for (int u = 0; u < NSET; ++u) load_set(u);
         int ks = 0;
-        for (; ks + 2 * NSET <= nks; ks += NSET) {
+        for (; ks + 2 * NSET <= nk; ks += NSET) {
 #pragma unroll
-            for (int u = 0; u < NSET; ++u) { step(u); load_set(u); }
+            for (int u = 0; u < NSET; ++u) { step(u, ks + u); load_set(u); }
         }
 #pragma unroll
         for (int u = 0; u < NSET; ++u) {
-            if (ks + u < nks) step(u);
-            if (ks + u + NSET < nks) load_set(u);
+            if (ks + u < nk) step(u, ks + u);
+            if (ks + u + NSET < nk) load_set(u);
         }
         ks += NSET;
 #pragma unroll
         for (int u = 0; u < NSET; ++u)
-            if (ks + u < nks) step(u);
-    }
-    {
-        // the K0 low-rank rows: A operand = the wave's C block, B operand = the layer-0 input rows without their slots 0 / 1
-        const T* Xl = A.XL + (size_t)w * A.xl_ws + (size_t)tile * A.xl_ts + (size_t)lq * P + lr;
-        const T* Ml = A.M0 + (size_t)w * A.m0_ws + (size_t)lq * P + lr;
-        const T* Ca = Cl + lr * NCP + lq;
-        auto rows = [&](const T* Xp, int nk, int c0) {
-            for (int ks = 0; ks < nk; ++ks) {
-                T av[NB], bv[ST];
-#pragma unroll
-                for (int s = 0; s < ST; ++s) bv[s] = Xp[(size_t)(4 * ks) * P + 16 * s];
-                bv[0] = lr < 2 ? T(0) : bv[0];
-#pragma unroll
-                for (int a = 0; a < NB; ++a) av[a] = Ca[16 * a * NCP + c0 + 4 * ks];
-#pragma unroll
-                for (int a = 0; a < NB; ++a)
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[a], bv[s], acc[a][s]);
-            }
-        };
-        rows(Xl, A.K0loc / 4, 0);
-        rows(Ml, A.K0sh / 4, A.K0loc);
+            if (ks + u < nk) step(u, ks + u);
         // columns K0, K0 + 1 of C go to slots 0, 1: one k-step on slot tile 0 with unit rows (lane groups 2, 3 contribute zeros)
         const T one = (lq == 0 && lr == 0) || (lq == 1 && lr == 1) ? T(1) : T(0);
 #pragma unroll
         for (int a = 0; a < NB; ++a) acc[a][0] = mfma16(Ca[16 * a * NCP + K0], one, acc[a][0]);
     }
     T* Got = A.Gout + (size_t)w * A.go_ws + (size_t)tile * A.go_ts + lr;
-    layer_epilogue<T, NB, ST, (RES ? 2 : 1), 0>(acc, G1t + lr, Got, (const T*)nullptr, n0, lane, P);
+    if constexpr (NOG1 && RES) {
+        // residual rows = layer-0 output rows n0 .. of this electron, recomputed per 16-row block: z0 = S0 + W0^T X0 (K0loc rows),
+        // G1[n][s] = y'_n z0[n][s] for s >= 2, (y_n, oL_n) in slots 0 / 1
+        const T* Xl = A.XL + (size_t)w * A.xl_ws + (size_t)tile * A.xl_ts + (size_t)lq * P + lr;
+        const T* S0p = A.S0 + (size_t)w * Kh * P + lr;
+        auto rf = [&](int a) {
+            const T rs2 = T(0.70710678118654752440);
+            // (at most five slot tiles at a time: the recomputed rows then take 40 registers next to the accumulators)
+#pragma unroll
+            for (int c0 = 0; c0 < ST; c0 += 5) {
+                constexpr int CWMAX = ST < 5 ? ST : 5;
+                const int cw = ST - c0 < 5 ? ST - c0 : 5;
+                acc_t racc[CWMAX];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int n = n0 + 16 * a + acc_row<T>(lane, rr);
+#pragma unroll
+                    for (int s = 0; s < CWMAX; ++s)
+                        if (s < cw) racc[s][rr] = S0p[(size_t)n * P + 16 * (c0 + s)];
+                }
+                for (int ks = 0; ks < A.K0loc / 4; ++ks) {
+                    const T av = A.W0[(size_t)(4 * ks + lq) * Kh + n0 + 16 * a + lr];
+#pragma unroll
+                    for (int s = 0; s < CWMAX; ++s)
+                        if (s < cw) racc[s] = mfma16(av, Xl[(size_t)(4 * ks) * P + 16 * (c0 + s)], racc[s]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + 16 * a + acc_row<T>(lane, r);
+                    typedef T vec2 __attribute__((ext_vector_type(2)));
+                    const vec2 yo = *reinterpret_cast<const vec2*>(yl + 2 * n);
+                    const T d1 = 1 - yo[0] * yo[0];
+#pragma unroll
+                    for (int s = 0; s < CWMAX; ++s)
+                        if (s < cw) {
+                            T hv = d1 * racc[s][r];
+                            if (c0 + s == 0) hv = lr == 0 ? yo[0] : (lr == 1 ? yo[1] : hv);
+                            __builtin_nontemporal_store((hv + acc[a][c0 + s][r]) * rs2, &Got[(size_t)n * P + 16 * (c0 + s)]);
+                        }
+                }
+            }
+        };
+        layer_epilogue<T, NB, ST, 2, 0>(acc, (const T*)nullptr, Got, (const T*)nullptr, n0, lane, P, rf);
+    } else
+        layer_epilogue<T, NB, ST, (RES ? 2 : 1), 0>(acc, G1t + lr, Got, (const T*)nullptr, n0, lane, P);
+}
+
+// Layer 0 in front of the low-rank layer 1: its dense output is never written.  k_jet_gemm<.., EPI 9> leaves, per electron, the two
+// numbers the low-rank form needs, YO[n] = (y_n = tanh z_n0, oL_n = y' z_nL + y'' sum_d z_nd^2); this kernel forms the mean of the
+// dense output over the electrons of each spin (the input of layer 1's shared term), in electron order, from YO and the layer-0 input:
+//     o_i[n][s] = y'_in (S0[n][s] + sum_k W0[k][n] X_i[k][s])   (s >= 2),   (y_in, oL_in) in slots 0 / 1
+//   grid (nch * Nout / 64 * slot chunks, walkers): four waves of 16 features x STC slot tiles (no coupling between slot chunks here).
+template <typename T, int STC>
+__global__ void __launch_bounds__(256, (sizeof(T) == 8 ? 3 : 4))
+k_layer0_means(SysDev<T> S, const T* __restrict__ XL, size_t xl_ws, size_t xl_ts, const T* __restrict__ W0, int K0loc,
+               const T* __restrict__ S0, int Nout, int P, const T* __restrict__ YO, T* __restrict__ MEAN1) {
+    typedef typename Acc4<T>::type acc_t;
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    const int ntile = P / 16, nck = (ntile + STC - 1) / STC, nfb = gridDim.x / (S.nch * nck);
+    const int chunk = blockIdx.x % nck, fb = (blockIdx.x / nck) % nfb, sp = blockIdx.x / (nck * nfb), w = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int n0 = (fb * 4 + wave) * 16, nks = K0loc / 4, t0 = chunk * STC;
+    if (n0 >= Nout) return;
+    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn;
+    const T* W0p = W0 + (size_t)lq * Nout + n0 + lr;
+    // the chunk's tile of the shared term stays in registers (padding tiles beyond the last one read tile ntile - 1 and are not stored)
+    acc_t s0[STC], macc[STC];
+#pragma unroll
+    for (int s = 0; s < STC; ++s) {
+        const int t = t0 + s < ntile ? t0 + s : ntile - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s0[s][r] = S0[(size_t)w * Nout * P + (size_t)(n0 + acc_row<T>(lane, r)) * P + 16 * t + lr];
+        macc[s] = acc_t{0, 0, 0, 0};
+    }
+    for (int e = 0; e < ns; ++e) {
+        const int i = i0 + e;
+        const T* Xl = XL + (size_t)w * xl_ws + (size_t)i * xl_ts + (size_t)lq * P + lr;
+        const T* yo = YO + ((size_t)w * S.N + i) * 2 * Nout;
+        vec2 yv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[r] = *reinterpret_cast<const vec2*>(yo + 2 * (n0 + acc_row<T>(lane, r)));
+        acc_t acc[STC];
+#pragma unroll
+        for (int s = 0; s < STC; ++s) acc[s] = s0[s];
+        for (int ks = 0; ks < nks; ++ks) {
+            const T wv = W0p[(size_t)(4 * ks) * Nout];
+            T xv[STC];
+#pragma unroll
+            for (int s = 0; s < STC; ++s) xv[s] = Xl[(size_t)(4 * ks) * P + 16 * (t0 + s < ntile ? t0 + s : ntile - 1)];
+#pragma unroll
+            for (int s = 0; s < STC; ++s) acc[s] = mfma16(wv, xv[s], acc[s]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const T y = yv[r][0], d1 = 1 - y * y;
+#pragma unroll
+            for (int s = 0; s < STC; ++s) {
+                T o = d1 * acc[s][r];
+                if (s == 0 && chunk == 0) o = lr == 0 ? y : (lr == 1 ? yv[r][1] : o);
+                macc[s][r] += o;
+            }
+        }
+    }
+    const T inv = T(1) / T(ns);
+    T* Mp = MEAN1 + ((size_t)w * S.nch + sp) * Nout * P + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + acc_row<T>(lane, r);
+#pragma unroll
+        for (int s = 0; s < STC; ++s)
+            if (t0 + s < ntile) Mp[(size_t)n * P + 16 * (t0 + s)] = macc[s][r] * inv;
+    }
+}
+
+// The two kernels above in one, for slot ranges that fit a wave's registers (ST <= 5) and NKS = K0loc / 4 known at compile time:
+// a wave owns 16 features x all slot tiles and walks the electrons of its spin; the input rows of electron e + 1 are requested
+// before the products of electron e.  (y, oL) -> YO, spin means of the dense output -> MEAN1; the dense output stays in registers.
+//   grid (nch * Nout / 64, walkers), four waves.
+template <typename T, int ST, int NKS>
+__global__ void __launch_bounds__(256, 2)
+k_layer0_stats(SysDev<T> S, const T* __restrict__ XL, size_t xl_ws, size_t xl_ts, const T* __restrict__ W0,
+               const T* __restrict__ S0, int Nout, int P, T* __restrict__ YO, T* __restrict__ MEAN1) {
+    typedef typename Acc4<T>::type acc_t;
+    const int nfb = gridDim.x / S.nch, sp = blockIdx.x / nfb, fb = blockIdx.x - sp * nfb, w = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    const int n0 = (fb * 4 + wave) * 16;
+    if (n0 >= Nout) return;
+    const int i0 = sp == 0 ? 0 : S.n_up, ns = sp == 0 ? S.n_up : S.n_dn;
+    T wv[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) wv[ks] = W0[(size_t)(4 * ks + lq) * Nout + n0 + lr];
+    acc_t s0[ST], macc[ST];
+#pragma unroll
+    for (int t = 0; t < ST; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s0[t][r] = S0[(size_t)w * Nout * P + (size_t)(n0 + acc_row<T>(lane, r)) * P + 16 * t + lr];
+        macc[t] = acc_t{0, 0, 0, 0};
+    }
+    const T* Xw = XL + (size_t)w * xl_ws + (size_t)lq * P + lr;
+    T xn[NKS][ST];
+    auto load_x = [&](int i) {
+        const T* Xl = Xw + (size_t)i * xl_ts;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < ST; ++t) xn[ks][t] = Xl[(size_t)(4 * ks) * P + 16 * t];
+    };
+    load_x(i0);
+    for (int e = 0; e < ns; ++e) {
+        const int i = i0 + e;
+        acc_t acc[ST];
+#pragma unroll
+        for (int t = 0; t < ST; ++t) acc[t] = s0[t];
+        T xc[NKS][ST];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < ST; ++t) xc[ks][t] = xn[ks][t];
+        load_x(i0 + (e + 1 < ns ? e + 1 : e));          // (unconditional: the last electron is requested twice)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int t = 0; t < ST; ++t) acc[t] = mfma16(wv[ks], xc[ks][t], acc[t]);
+        T* yo = YO + ((size_t)w * S.N + i) * 2 * Nout;
+        // tanh of the four value slots in one evaluation (lane lr < 4 of every row takes row group lr)
+        T zsel = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const T v = row16_bcast<0>(acc[0][r]);
+            zsel = lr == r ? v : zsel;
+        }
+        const T yall = ds_tanh(zsel);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + acc_row<T>(lane, r);
+            T ss = 0;
+#pragma unroll
+            for (int t = 0; t < ST; ++t) ss += (16 * t + lr >= 2) ? acc[t][r] * acc[t][r] : T(0);
+            ss = row16_sum(ss);
+            const T y = row16_bcast_dyn<4>(yall, r), d1 = 1 - y * y, d2 = -2 * y * d1;
+            const T oL = d1 * row16_bcast<1>(acc[0][r]) + d2 * ss;
+            if (lr < 2) yo[2 * n + lr] = lr == 0 ? y : oL;
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                T o = d1 * acc[t][r];
+                if (t == 0) o = lr == 0 ? y : (lr == 1 ? oL : o);
+                macc[t][r] += o;
+            }
+        }
+    }
+    const T inv = T(1) / T(ns);
+    T* Mp = MEAN1 + ((size_t)w * S.nch + sp) * Nout * P + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + acc_row<T>(lane, r);
+#pragma unroll
+        for (int t = 0; t < ST; ++t) Mp[(size_t)n * P + 16 * t] = macc[t][r] * inv;
+    }
 }
 
 // W0T[n][c] (c < NCW): the layer-0 weight of input row c for output feature n -- per-electron rows, then the shared rows, zero beyond
