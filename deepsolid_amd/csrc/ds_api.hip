@@ -13,7 +13,27 @@
 
 #include "../../include/deepsolid_hip.h"
 #include "ds_grad.h"
+#include "ds_tiles.h"
 #include "ds_mcmc.h"
+
+// the per-slot-tile-count kernel instances live in ds_tiles_inst.hip (five slot-tile ranges x two element types)
+namespace ds {
+#define DS_DECL(p) const TileOps<double>* tile_ops_f64_p##p(int); const TileOps<float>* tile_ops_f32_p##p(int);
+DS_DECL(0) DS_DECL(1) DS_DECL(2) DS_DECL(3) DS_DECL(4)
+#undef DS_DECL
+template <> const TileOps<double>* tile_ops<double>(int st) {
+    const TileOps<double>* (*parts[])(int) = {tile_ops_f64_p0, tile_ops_f64_p1, tile_ops_f64_p2, tile_ops_f64_p3, tile_ops_f64_p4};
+    for (auto f : parts)
+        if (const TileOps<double>* o = f(st)) return o;
+    return nullptr;
+}
+template <> const TileOps<float>* tile_ops<float>(int st) {
+    const TileOps<float>* (*parts[])(int) = {tile_ops_f32_p0, tile_ops_f32_p1, tile_ops_f32_p2, tile_ops_f32_p3, tile_ops_f32_p4};
+    for (auto f : parts)
+        if (const TileOps<float>* o = f(st)) return o;
+    return nullptr;
+}
+}  // namespace ds
 
 namespace {
 
@@ -79,7 +99,6 @@ struct ds_system {
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
-    bool lr_keep_g1 = false;          // DS_LR_KEEP_G1: layer 0 still writes its dense output (the low-rank layer reads y, oL and the residual from it)
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
     int dbg = 0;                      // DS_DBG (kernel development): 32 = phase stamps of one wave; 1 / 2 switch arithmetic off in a `make EXP=1` build only
@@ -333,26 +352,6 @@ template <typename T> Carve<T> carve(const ds_system* s, void* ws, int64_t Bc) {
 }
 
 // ---------------------------------------------------------------- launch helpers
-template <typename T, typename F> int dispatch_tiles(int st_tiles, F&& f) {
-    // (NB, ST): 16*NB output features x 16*ST slots per wave; accumulators = NB*ST tiles
-    switch (st_tiles) {
-        case 1: f(std::integral_constant<int, 4>(), std::integral_constant<int, 1>()); return 0;
-        case 2: f(std::integral_constant<int, 4>(), std::integral_constant<int, 2>()); return 0;
-        case 3: f(std::integral_constant<int, 4>(), std::integral_constant<int, 3>()); return 0;
-        case 4: f(std::integral_constant<int, 4>(), std::integral_constant<int, 4>()); return 0;
-        case 5: f(std::integral_constant<int, 4>(), std::integral_constant<int, 5>()); return 0;
-        case 6: f(std::integral_constant<int, 2>(), std::integral_constant<int, 6>()); return 0;
-        case 7: f(std::integral_constant<int, 2>(), std::integral_constant<int, 7>()); return 0;
-        case 8: f(std::integral_constant<int, 2>(), std::integral_constant<int, 8>()); return 0;
-        case 9: f(std::integral_constant<int, 2>(), std::integral_constant<int, 9>()); return 0;
-        case 10: f(std::integral_constant<int, 2>(), std::integral_constant<int, 10>()); return 0;
-        // 96 electrons: 16 features x 304 slots per wave in float64, 32 features in float32 (152 accumulator registers either way;
-        // larger tiles need AGPR accumulators and spill)
-        case 19: f(std::integral_constant<int, (sizeof(T) == 4 ? 2 : 1)>(), std::integral_constant<int, 19>()); return 0;
-        default: return 1;
-    }
-}
-
 // workgroup size and grid.z of k_jet_gemm<NB>: at most 1024/NB threads (= its launch bound) per workgroup
 inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz, int ST = 0) {
     const int nw = Nout / (16 * NB), wmax = (NB == 3 || ST > 5) ? 4 : 1024 / NB / 64;
@@ -394,15 +393,18 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     Carve<T> c = carve<T>(s, ws, Bc);
     auto blk = [&](int i) { return params + s->blocks[i].offset; };
     const int stop = dr ? dr->stop : STOP_NONE;
+    // the kernels instantiated per jet-slot tile count (ds_tiles.h)
+    const ds::TileOps<T>* to = ds::tile_ops<T>(S.P / 16);
+    if (!to) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
+    const int NB = to->NB, ST = to->ST;
     // Low-rank first hidden layer (k_layer1_lr): layer 0 reads its input tiles from their own buffer XL (layer 1 needs them again
-    // while it overwrites G[0]); off for the stage dumps, which show the dense path's buffers.
+    // while it overwrites G[0]) and does not write its dense output -- k_layer0_stats leaves (y, oL) per electron and the spin means
+    // of the output (the input of layer 1's shared term), layer 1 recomputes its residual rows from the layer-0 input.  Off for the
+    // stage dumps, which show the dense path's buffers.
     const int K0loc = S.h1[0] + S.nch * S.h2[0], K0sh = S.nch * S.h1[0];
     const int lr_nc = std::max(2, (K0loc + K0sh + 4 + 15) / 16);      // column tiles of the per-electron weights C (instances: 2, 3, 4)
     const bool lr_on = s->use_lr && !dr && S.n_layers >= 2 && lr_nc <= 4 && S.h1[1] % 16 == 0 && (S.nch * S.h2[1]) % 4 == 0 &&
                        3 * (K0loc + K0sh + 4) <= S.h1[1];
-    // ... and the dense layer-0 output is not written at all: k_layer0_stats leaves (y, oL) per electron and the spin means of
-    // the output (the input of layer 1's shared term); layer 1 recomputes its residual rows from the layer-0 input.
-    const bool lr_nog1 = lr_on && !s->lr_keep_g1;
     // 1. features
     {
         ProfScope ps(s, DS_PROF_FEATURES, st);
@@ -449,31 +451,28 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
         const bool res = Kh == Nout;
         if (res && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
-        int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
-            constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
+        {
             dim3 block; unsigned gz;
             gemm_geom(Nout, NB, &block, &gz, ST);
             const size_t gws = (size_t)S.N * S.ldk * S.P, gts = (size_t)S.ldk * S.P;
-            T* Sl = (lr_nog1 && l == 1) ? c.ZB + (size_t)Bc * S.h1[1] * S.P : c.ZB;      // this layer's shared term
+            T* Sl = (lr_on && l == 1) ? c.ZB + (size_t)Bc * S.h1[1] * S.P : c.ZB;      // this layer's shared term
             {
                 // shared spin-mean term S (one tile per walker): layer 0 from the MEAN buffer of k_features,
                 // hidden layers straight from the electron rows of G (means formed on the fly)
                 ProfScope ps(s, DS_PROF_SHARED_TERM, st);
-                if (l == 0)
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
-                                       (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[0], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
-                                       c.ZB, (size_t)Nout * S.P, (size_t)0, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
-                else if (lr_nog1 && l == 1)
-                    // the spin means of the layer-0 output came out of k_layer0_stats (MEAN[1]); S of layer 0 stays in front of this one
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 6>), dim3(1, (unsigned)Bc, gz), block, 0, st, (const T*)nullptr,
-                                       (size_t)0, (size_t)0, (const T*)nullptr, 0, c.MEAN[1], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
-                                       Sl, (size_t)Nout * S.P, (size_t)0, Nout, S.P, (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
-                else {
+                if (l == 0 || (lr_on && l == 1)) {
+                    // a plain product on ready spin means: those of the input features (MEAN[0], k_features), or -- in front of the
+                    // low-rank layer 1 -- those of the layer-0 output (MEAN[1], k_layer0_stats); S of layer 0 stays in front of S of layer 1
+                    const ds::GemmArgs<T> ga{nullptr, 0, 0, nullptr, 0, l == 0 ? c.MEAN[0] : c.MEAN[1], (size_t)Ksh * S.P, blk(s->i_wsh[l]), Ksh, 0,
+                                             Sl, (size_t)Nout * S.P, 0, Nout, S.P, nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{}};
+                    to->gemm(6, dim3(1, (unsigned)Bc, gz), block, st, ga);
+                } else {
                     // (its own geometry: as many waves per workgroup as possible, every workgroup re-forms the spin means)
                     dim3 sblock; unsigned sgz;
                     gemm_geom(Nout, NB, &sblock, &sgz);
-                    hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, sgz), sblock, 2 * 16 * S.P * sizeof(T), st, S,
-                                       c.G[gi], blk(s->i_wsh[l]), Kh, Sl, Nout, S.P, blk(s->i_b[l]), 0);
+                    if (ST > 10 && sblock.x > 512) { sblock = dim3(512); sgz = (unsigned)((Nout / (16 * NB) + 7) / 8); }      // (k_shared_term's launch bound for wide slot ranges)
+                    to->shared_term(dim3(1, (unsigned)Bc, sgz), sblock, 2 * 16 * S.P * sizeof(T), st, S, c.G[gi], blk(s->i_wsh[l]), Kh, Sl, Nout, S.P,
+                                    blk(s->i_b[l]), 0);
                 }
             }
             {
@@ -482,52 +481,38 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             // layer input tiles: G[gi], or (layer 0 in front of the low-rank layer 1) the XL buffer
             const T* Xin = (lr_on && l == 0) ? c.XL : c.G[gi];
             const size_t xws = (lr_on && l == 0) ? (size_t)S.N * K0loc * S.P : gws, xts = (lr_on && l == 0) ? (size_t)K0loc * S.P : gts;
+            const dim3 lgrid(S.N * gz, (unsigned)Bc, 1);
+            ds::GemmArgs<T> ga{Xin, xws, xts, blk(s->i_wloc[l]), Kloc, nullptr, 0, nullptr, 0, S.N, c.G[gi ^ 1], gws, gts, Nout, S.P, c.ZB, blk(s->i_b[l]),
+                               ds::OrbEpi<T>{}};
             if (lr_on && l == 1) {
                 // first hidden layer on the low-rank form of the layer-0 output (ds_gemm.h: k_layer1_lr)
-                ds::LrArgs<T> la{c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, c.MEAN[0], (size_t)K0sh * S.P, K0loc, K0sh,
-                                 (const T*)s->lr_w0t, c.G[gi], gws, gts, blk(s->i_wloc[l]), Kh, S.nch * K2, c.G[gi ^ 1], gws, gts, Sl,
-                                 Nout, S.P, S.N, c.YO, L.YO, blk(s->i_wloc[0]), c.ZB};
-                const dim3 lgrid(S.N * gz, (unsigned)Bc, 1);
-#define DS_LR(NCV, RESV, NOG) hipLaunchKernelGGL((ds::k_layer1_lr<T, NB, ST, NCV, RESV, NOG>), lgrid, block, (ds::lr_lds_bytes<T, NB, NCV>(block.x, Kh)), st, la)
-#define DS_LR2(NCV) do { if (lr_nog1) { if (res) DS_LR(NCV, true, true); else DS_LR(NCV, false, true); } else { if (res) DS_LR(NCV, true, false); else DS_LR(NCV, false, false); } } while (0)
-                if (lr_nc <= 2) DS_LR2(2); else if (lr_nc == 3) DS_LR2(3); else DS_LR2(4);
-#undef DS_LR2
-#undef DS_LR
-            } else if (lr_nog1 && l == 0) {
-                // layer 0 without its dense output: (y, oL) per electron + the spin means of the output (ds_gemm.h)
-                const int nks0 = K0loc / 4;
-                bool one_kernel = false;
-                if constexpr (ST <= 5) {
-                    // one kernel when a wave holds all slot tiles of 16 features (k_layer0_stats)
-                    const dim3 sgrid(S.nch * (unsigned)((Nout + 63) / 64), (unsigned)Bc);
-#define DS_L0S(NKSV) hipLaunchKernelGGL((ds::k_layer0_stats<T, ST, NKSV>), sgrid, dim3(256), 0, st, S, c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, \
-                                        blk(s->i_wloc[0]), c.ZB, Nout, S.P, c.YO, c.MEAN[1])
-                    one_kernel = nks0 >= 2 && nks0 <= 4;
-                    if (nks0 == 2) DS_L0S(2); else if (nks0 == 3) DS_L0S(3); else if (nks0 == 4) DS_L0S(4);
-#undef DS_L0S
-                }
+                const ds::LrArgs<T> la{c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, c.MEAN[0], (size_t)K0sh * S.P, K0loc, K0sh,
+                                       (const T*)s->lr_w0t, c.G[gi], gws, gts, blk(s->i_wloc[l]), Kh, S.nch * K2, c.G[gi ^ 1], gws, gts, Sl,
+                                       Nout, S.P, S.N, c.YO, L.YO, blk(s->i_wloc[0]), c.ZB, s->dbg >> 8};
+                to->layer1_lr(lr_nc, res, lgrid, block, st, la);
+            } else if (lr_on && l == 0) {
+                // layer 0 without its dense output: (y, oL) per electron + the spin means of the output (ds_gemm.h).  One kernel when
+                // a wave holds all slot tiles of 16 features (k_layer0_stats) ...
+                const bool one_kernel = to->layer0_stats &&
+                    to->layer0_stats(K0loc / 4, dim3(S.nch * (unsigned)((Nout + 63) / 64), (unsigned)Bc), st, S, c.XL, (size_t)S.N * K0loc * S.P,
+                                     (size_t)K0loc * S.P, blk(s->i_wloc[0]), c.ZB, Nout, S.P, c.YO, c.MEAN[1]);
                 if (!one_kernel) {
-                    // (y, oL) from the layer kernel with the output dropped (EPI 9), then the means per slot chunk (k_layer0_means)
-                    hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 9>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, Xin, xws, xts,
-                                       blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.YO, L.YO, (size_t)2 * Nout, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+                    // ... otherwise (y, oL) from the layer kernel with the output dropped (EPI 9), then the means per slot chunk (k_layer0_means)
+                    ga.Z = c.YO; ga.zws = L.YO; ga.zts = (size_t)2 * Nout;
+                    to->gemm(9, lgrid, block, st, ga);
                     constexpr int STC = 5;
                     const unsigned nfb = (unsigned)((Nout + 63) / 64), nck = (unsigned)((S.P / 16 + STC - 1) / STC);
                     hipLaunchKernelGGL((ds::k_layer0_means<T, STC>), dim3(S.nch * nfb * nck, (unsigned)Bc), dim3(256), 0, st, S, c.XL,
                                        (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, blk(s->i_wloc[0]), K0loc, c.ZB, Nout, S.P, c.YO, c.MEAN[1]);
                 }
             } else if (res) {
-                ds::OrbEpi<T> oe_clk{};
-                oe_clk.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
-                if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { oe_clk.clk = s->clk_dev; oe_clk.dbg = s->dbg; }
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 2>), dim3(S.N * gz, (unsigned)Bc, 1), block, (ds::gemm_stash_bytes<T, NB, ST>(block.x)), st, Xin, xws, xts,
-                                   blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1], gws, gts, Nout, S.P, c.ZB, blk(s->i_b[l]), oe_clk);
+                ga.oe.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
+                if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }
+                to->gemm(2, lgrid, block, st, ga);
+            } else
+                to->gemm(1, lgrid, block, st, ga);
             }
-            else
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 1>), dim3(S.N * gz, (unsigned)Bc, 1), block, 0, st, Xin, xws, xts,
-                                   blk(s->i_wloc[l]), Kloc, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, c.G[gi ^ 1], gws, gts, Nout, S.P, c.ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
-            }
-        });
-        if (rc) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
+        }
         gi ^= 1;
         if (l < S.n_double) {
             hi ^= 1;
@@ -546,35 +531,29 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
         const int Korb = Kl + (s->use_last ? S.nch * K2l : 0);
         if (Korb % 16) return fail("orbital head with K = %d: the GEMM's operand ring needs K %% 16 == 0", Korb);
-        int rc = dispatch_tiles<T>(S.P / 16, [&](auto nb, auto stt) {
-            constexpr int NB = decltype(nb)::value, ST = decltype(stt)::value;
+        {
             dim3 block; unsigned gz;
             gemm_geom(OC, NB, &block, &gz, ST);
             if (s->use_last) {
                 ProfScope ps(s, DS_PROF_SHARED_TERM, st);
-                hipLaunchKernelGGL((ds::k_shared_term<T, NB, ST>), dim3(1, (unsigned)Bc, gz), block, 2 * 16 * S.P * sizeof(T), st, S, c.G[gi],
-                                   blk(s->i_wsh_orb[sp]), Kl, c.ZB, OC, S.P, (const T*)nullptr, 0);
+                to->shared_term(dim3(1, (unsigned)Bc, gz), block, 2 * 16 * S.P * sizeof(T), st, S, c.G[gi], blk(s->i_wsh_orb[sp]), Kl, c.ZB, OC, S.P,
+                                (const T*)nullptr, 0);
             }
             ProfScope ps(s, DS_PROF_ORBITAL, st);
             const int ch = S.mat_ch[sp];
-            ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
-                             S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
+            const ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
+                                   S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
+            const ds::GemmArgs<T> ga{c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P, blk(s->i_worb[sp]), Korb,
+                                     nullptr, 0, nullptr, 0, ns, nullptr, 0, 0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, nullptr, oe};
             // 192 columns (n_s*K = 96) would give 3 waves of 64 columns per workgroup and leave SIMDs with a single wave;
             // 48-column waves give 4 balanced waves (the MFMA pipe needs >= 2 waves per SIMD, profiles/r01_mfma_f64_probe.json)
-            if (NB == 4 && ST <= 5 && OC % 256 != 0 && OC % 192 == 0) {
+            if (to->gemm_orb3 && OC % 256 != 0 && OC % 192 == 0) {
                 dim3 b3; unsigned gz3;
                 gemm_geom(OC, 3, &b3, &gz3);
-                hipLaunchKernelGGL((ds::k_jet_gemm<T, 3, (ST <= 5 ? ST : 1), 5>), dim3(ns * gz3, (unsigned)Bc, 1), b3, 0, st,
-                                   c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
-                                   blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
-                                   (size_t)0, (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
+                to->gemm_orb3(dim3(ns * gz3, (unsigned)Bc, 1), b3, st, ga);
             } else
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, NB, ST, 5>), dim3(ns * gz, (unsigned)Bc, 1), block, 0, st,
-                               c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P,
-                               blk(s->i_worb[sp]), Korb, (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, ns, (T*)nullptr,
-                               (size_t)0, (size_t)0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, (const T*)nullptr, oe);
-        });
-        if (rc) return fail("no orbital kernel instance for %d slot tiles", S.P / 16);
+                to->gemm(5, dim3(ns * gz, (unsigned)Bc, 1), block, st, ga);
+        }
     }
     if (stop == STOP_MOUT) return copy_out(dr, c.MOUT, L.MOUT * Bc, st);
     // determinants
@@ -1318,8 +1297,8 @@ int check_arch(const ds_system_desc* d) {
     // every shape limit of the kernels is checked HERE, so that a handle that was created never fails at its first launch
     const int N = d->n_up + d->n_dn, tiles = (3 * N + 2 + 15) / 16, nmat = d->full_det ? N : std::max(d->n_up, d->n_dn);
     if (nmat > 64) return fail("determinant matrices larger than 64 x 64 are not supported (n = %d): the trace kernels keep a matrix row per lane group", nmat);
-    if (!((tiles >= 1 && tiles <= 10) || tiles == 19))
-        return fail("no kernel instance for %d jet-slot tiles (N = %d electrons): supported are N <= 52 and 96 <= N <= 100", tiles, N);
+    if (tiles < 1 || tiles > ds::DS_MAX_TILES)
+        return fail("no kernel instance for %d jet-slot tiles (N = %d electrons): supported are N <= 132", tiles, N);
     const int n_double = d->use_last_layer ? d->n_layers : d->n_layers - 1;
     const int nch = d->n_dn > 0 ? 2 : 1;
     for (int l = 0; l < d->n_layers; ++l) {
@@ -1343,6 +1322,9 @@ const char* ds_last_error(void) { return g_err.c_str(); }
 int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     if (!desc || !out) return fail("null argument");
     if (int rc = check_arch(desc)) return rc;
+    if (!desc->prim_atoms || !desc->klist_up || (desc->n_dn > 0 && !desc->klist_dn) || !desc->sim_atoms || !desc->sim_charges ||
+        (desc->n_g > 0 && (!desc->gpoints || !desc->gweight || !desc->ion_exp_re || !desc->ion_exp_im)))
+        return fail("null array pointer in ds_system_desc");
     ds_system* s = new ds_system();
     s->d = *desc;
     s->dtype = desc->dtype;
@@ -1383,7 +1365,6 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
-    s->lr_keep_g1 = getenv("DS_LR_KEEP_G1") != nullptr;
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     // (grid.y carries the walker index: at most 65535 walkers per launch)
     if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::min<int64_t>(65535, std::max<int64_t>(1, atol(e)));

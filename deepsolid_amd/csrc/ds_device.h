@@ -100,7 +100,7 @@ template <int N, typename T> __device__ __forceinline__ T row16_bcast_dyn(T v, i
 // 3.5e-16 (the host libm: 3.0e-16).  ~45 instructions.
 // (the coefficients come from constant memory through scalar loads: as literals every one of them would occupy a VGPR pair
 //  that the compiler hoists out of the surrounding loops -- ~36 registers held for the whole kernel)
-__device__ __constant__ double DS_TANH_C[16] = {
+static __device__ __constant__ double DS_TANH_C[16] = {
     1.0 / 87178291200.0, 1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
     1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 1.4426950408889634074, -6.93147180369123816490e-01,
     -1.90821492927058770002e-10, 80.0};

@@ -441,28 +441,29 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 //     phase 2   Z = C X0' (A operand from the wave's LDS copy of C; X0' = X0 with its value / Laplacian slots zeroed, plus the two
 //               unit rows that route C[:, K0], C[:, K0 + 1] to slots 0 / 1) + W1_m^T M2: (K0 + 4 + Km2) / 4 k-steps of NB x ST
 // instead of (Kh + Km2) / 4 k-steps of NB x ST: at 24 electrons 952 MFMAs per wave tile instead of 1600.  The epilogue is the one of
-// k_jet_gemm (EPI 1 / 2); the residual rows are read from G1.
+// k_jet_gemm (EPI 1 / 2); the residual rows (= layer-0 output rows) are recomputed from the layer-0 input, 16 rows at a time.
 // =====================================================================================
 template <typename T> struct LrArgs {
     const T* XL; size_t xl_ws, xl_ts;    // layer-0 per-electron input rows [walker][tile][K0loc][P]
     const T* M0; size_t m0_ws;           // layer-0 shared input rows (spin means of the input features) [walker][K0sh][P]
     int K0loc, K0sh;                     // multiples of 4
     const T* W0T;                        // [Kh][16 NC]: W0T[n][c] = layer-0 weight of input row c (per-electron rows, then shared rows), 0 beyond
-    const T* G1; size_t g_ws, g_ts;      // layer-1 input tiles [walker][tile][rows][P]: slots 0 / 1 of rows < Kh = y, oL; rows Kh.. = pair means
+    const T* G1; size_t g_ws, g_ts;      // layer-1 input tiles [walker][tile][rows][P]: only rows Kh.. (the pair means) are written and read
     const T* W1; int Kh, Km2;            // layer-1 weights [Kh + Km2][Nout]
     T* Gout; size_t go_ws, go_ts;        // layer-1 output tiles
     const T* S1;                         // [walker][Nout][P] shared term of layer 1 (with its bias)
     int Nout, P, n_tiles;
-    // layer-0 output never written (NOG1): y, oL come from YO, the residual rows are recomputed from the layer-0 input
+    // the layer-0 output is never written: y, oL come from YO, the residual rows are recomputed from the layer-0 input
     const T* YO; size_t yo_ws;           // [walker][tile][Kh][2] = (y_n, oL_n)  (k_layer0_stats)
     const T* W0; const T* S0;            // layer-0 per-electron weights [K0loc][Kh], its shared term [walker][Kh][P]
+    int dbg;                             // timing experiments (make EXP=1 only): 1 no epilogue, 2 no phase 1, 4 no phase 2, 8 no S1 loads
 };
 template <int NB, int NC> constexpr int lr_ncp() { return 16 * NC + 1; }
 template <typename T, int NB, int NC> inline size_t lr_lds_bytes(unsigned threads, int Kh) {
     return ((size_t)2 * Kh + (size_t)(threads / 64) * 16 * NB * lr_ncp<NB, NC>()) * sizeof(T);
 }
 
-template <typename T, int NB, int ST, int NC, bool RES, bool NOG1>
+template <typename T, int NB, int ST, int NC, bool RES>
 __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)) k_layer1_lr(LrArgs<T> A) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int NCP = lr_ncp<NB, NC>();
@@ -490,8 +491,7 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
         typedef T vec2 __attribute__((ext_vector_type(2)));
         const T* yo = A.YO + (size_t)w * A.yo_ws + (size_t)tile * 2 * Kh;
         for (int n = threadIdx.x; n < Kh; n += blockDim.x)
-            *reinterpret_cast<vec2*>(yl + 2 * n) = NOG1 ? *reinterpret_cast<const vec2*>(yo + 2 * n)
-                                                        : *reinterpret_cast<const vec2*>(G1t + (size_t)n * P);      // slots 0, 1 (rows are 128-byte aligned)
+            *reinterpret_cast<vec2*>(yl + 2 * n) = *reinterpret_cast<const vec2*>(yo + 2 * n);
     }
     __syncthreads();
     if (n0 >= Nout) return;
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
 #pragma unroll
                 for (int s = 0; s < NC; ++s) c1[a][s] = mfma16(av[u][a], bv[s], c1[a][s]);
         };
-        const int nks = Kh / 4;                       // (Kh is a multiple of 16: launcher)
+        const int nks = DS_EXP(A.dbg & 2) ? 4 : Kh / 4;                       // (Kh is a multiple of 16: launcher)
 #pragma unroll
         for (int u = 0; u < 4; ++u) load_set(u);
         int ks = 0;
@@ -550,7 +550,12 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
     __builtin_amdgcn_wave_barrier();
     // ---------------- phase 2
     acc_t acc[NB][ST];
-    {
+    if (DS_EXP(A.dbg & 8)) {
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int s = 0; s < ST; ++s) acc[a][s] = acc_t{0, 0, 0, 0};
+    } else {
         const T* Sp0 = A.S1 + (size_t)w * Nout * P + lr;
 #pragma unroll
         for (int a = 0; a < NB; ++a)
@@ -569,7 +574,7 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
         // re-reads the last pair-mean row, the pointers are selected by the k-step index.
         constexpr int NSET = ring_sets<T, NB, ST>();
         T av[NSET][NB], bv[NSET][ST];
-        const int nm2 = A.Km2 / 4, nl = A.K0loc / 4, nk = nm2 + K0 / 4;
+        const int nm2 = A.Km2 / 4, nl = A.K0loc / 4, nk = DS_EXP(A.dbg & 4) ? 4 : nm2 + K0 / 4;
         const T* Wm = A.W1 + (size_t)(Kh + lq) * Nout + n0 + lr;
         const T* Xm = G1t + (size_t)(Kh + lq) * P + lr;
         const T* Xl = A.XL + (size_t)w * A.xl_ws + (size_t)tile * A.xl_ts + (size_t)lq * P + lr;
@@ -621,7 +626,16 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
         for (int a = 0; a < NB; ++a) acc[a][0] = mfma16(Ca[16 * a * NCP + K0], one, acc[a][0]);
     }
     T* Got = A.Gout + (size_t)w * A.go_ws + (size_t)tile * A.go_ts + lr;
-    if constexpr (NOG1 && RES) {
+    if (DS_EXP(A.dbg & 1)) {
+        T v = 0;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int s = 0; s < ST; ++s) v += acc[a][s][0] + acc[a][s][1] + acc[a][s][2] + acc[a][s][3];
+        if (v == T(12345.678)) Got[0] = v;
+        return;
+    }
+    if constexpr (RES) {
         // residual rows = layer-0 output rows n0 .. of this electron, recomputed per 16-row block: z0 = S0 + W0^T X0 (K0loc rows),
         // G1[n][s] = y'_n z0[n][s] for s >= 2, (y_n, oL_n) in slots 0 / 1
         const T* Xl = A.XL + (size_t)w * A.xl_ws + (size_t)tile * A.xl_ts + (size_t)lq * P + lr;
@@ -665,7 +679,7 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
         };
         layer_epilogue<T, NB, ST, 2, 0>(acc, (const T*)nullptr, Got, (const T*)nullptr, n0, lane, P, rf);
     } else
-        layer_epilogue<T, NB, ST, (RES ? 2 : 1), 0>(acc, G1t + lr, Got, (const T*)nullptr, n0, lane, P);
+        layer_epilogue<T, NB, ST, 1, 0>(acc, (const T*)nullptr, Got, (const T*)nullptr, n0, lane, P);
 }
 
 // Layer 0 in front of the low-rank layer 1: its dense output is never written.  k_jet_gemm<.., EPI 9> leaves, per electron, the two
@@ -835,7 +849,7 @@ __global__ void k_lr_w0t(const T* __restrict__ Wloc0, const T* __restrict__ Wsh0
 // a workgroup (one walker, NW waves of 16*NB features) sums the n_s electron rows of a 16-row K chunk into
 // LDS (each thread sums 32-byte pieces of the rows, fully coalesced), then every wave runs 4 k-steps on it.
 template <typename T, int NB, int ST>
-__global__ void __launch_bounds__(1024 / NB, (NB == 4 ? 2 : 1))
+__global__ void __launch_bounds__((ST > 10 ? 512 : 1024 / NB), (NB == 4 ? 2 : 1))      // (ST > 10: at most eight waves, so that a wave may hold 16 NB x 16 ST accumulators)
 k_shared_term(SysDev<T> S, const T* __restrict__ G, const T* __restrict__ Wsh, int Kh, T* __restrict__ Sb, int Nout, int P,
               const T* __restrict__ bias, int bias_all_slots) {
     typedef typename Acc4<T>::type acc_t;

@@ -1145,7 +1145,7 @@ template <typename T> __global__ void k_sum3(const T* __restrict__ t, long n, T*
 }
 
 // HBM counter calibration: a plain 8-byte-per-lane copy (the access width of every jet tensor load / store)
-__global__ void k_calib_copy(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+static __global__ void k_calib_copy(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 

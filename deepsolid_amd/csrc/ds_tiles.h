@@ -1,0 +1,37 @@
+// ds_tiles.h -- the kernels that are instantiated per jet-slot tile count ST = P / 16 (k_jet_gemm layer / orbital epilogues,
+// k_shared_term, k_layer1_lr, k_layer0_stats), reached through a table of launchers so that the instances can be compiled in
+// several translation units (ds_tiles_inst.hip, one per slot-tile range and element type) next to the host code (ds_api.hip).
+//   ST = 1 .. 25: N <= 128 electrons (matrices up to 64 x 64 per spin).  Wave tile = 16 NB features x 16 ST slots:
+//   NB = 4 for ST <= 5, 2 for ST <= 10, beyond that 1 (float64) / 2 (float32) with four waves per workgroup and one workgroup per CU.
+#pragma once
+#include "ds_gemm.h"
+
+namespace ds {
+
+template <typename T> struct GemmArgs {          // the arguments of k_jet_gemm
+    const T* X; size_t xws, xts; const T* W; int K; const T* X2; size_t x2ws; const T* W2; int K2; int n_tiles;
+    T* Z; size_t zws, zts; int Nout, P; const T* Sb; const T* bias; OrbEpi<T> oe;
+};
+
+template <typename T> struct TileOps {
+    int NB, ST;
+    // k_jet_gemm<T, NB, ST, epi> for epi = 1, 2, 5, 6, 9 (dynamic LDS of the residual stash added for epi 2)
+    void (*gemm)(int epi, dim3 grid, dim3 block, hipStream_t st, const GemmArgs<T>& a);
+    // k_jet_gemm<T, 3, ST, 5>: 48-column waves of the orbital head (ST <= 5), or null
+    void (*gemm_orb3)(dim3 grid, dim3 block, hipStream_t st, const GemmArgs<T>& a);
+    void (*shared_term)(dim3 grid, dim3 block, size_t lds, hipStream_t st, const SysDev<T>& S, const T* G, const T* Wsh, int Kh, T* Sb,
+                        int Nout, int P, const T* bias, int bias_all_slots);
+    // k_layer1_lr<T, NB, ST, nc, res> (nc = 2, 3, 4)
+    void (*layer1_lr)(int nc, bool res, dim3 grid, dim3 block, hipStream_t st, const LrArgs<T>& a);
+    // k_layer0_stats<T, ST, nks> (ST <= 5, nks = 2, 3, 4): returns false when there is no such instance; or null
+    bool (*layer0_stats)(int nks, dim3 grid, hipStream_t st, const SysDev<T>& S, const T* XL, size_t xl_ws, size_t xl_ts, const T* W0,
+                         const T* S0, int Nout, int P, T* YO, T* MEAN1);
+};
+
+constexpr int DS_MAX_TILES = 25;
+constexpr int tile_nb(int st, int elem_bytes) { return st <= 5 ? 4 : (st <= 10 ? 2 : (elem_bytes == 4 ? 2 : 1)); }
+
+// the table entry of a slot-tile count, or null (ds_api.hip; the parts are defined in ds_tiles_inst.hip)
+template <typename T> const TileOps<T>* tile_ops(int st_tiles);
+
+}  // namespace ds

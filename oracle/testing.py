@@ -133,4 +133,8 @@ CASES = {
                           samplers=False, ke_walkers=3, grad_walkers=3),
     'li_polarized':  dict(system='bcc_li', seed=30, batch=3, system_kw=dict(S=1, nelec=(3, 0)), mcmc=False, samplers=False,
                           ke_walkers=3, grad_walkers=3),
+    # supercells between and beyond the BASELINE sizes: 81 electrons (41 + 40: 16 jet-slot tiles, odd matrix size) and
+    # 108 electrons (54 + 54: 21 jet-slot tiles) -- ordinary DeepSolid cells (supercell.py:64-95, network.py:60-186)
+    'bcc_li_333':    dict(system='bcc_li', seed=35, batch=2, system_kw=dict(S=3), mcmc=False, samplers=False, ke_walkers=1),
+    'graphene_331':  dict(system='graphene', seed=36, batch=2, system_kw=dict(S=3), mcmc=False, samplers=False, ke_walkers=1),
 }

@@ -115,8 +115,9 @@ def test_philox_known_answers_and_moments():
 def test_shape_limits_are_rejected_at_create():
     """Every shape the kernels cannot run is refused by ds_system_create itself (check_arch runs before any device
     allocation, so this needs no GPU): a handle that was created never fails at its first launch.  The supported set is
-    documented in DESIGN.md section 1: determinant matrices up to 64 x 64, N <= 52 or 96..100 electrons (jet-slot tiles
-    1..10 and 19), hidden_single multiples of 64 up to 1024, hidden_double 16 or 32, up to 32 determinants."""
+    documented in DESIGN.md section 1: determinant matrices up to 64 x 64 (hence N <= 128 electrons, or 64 with full_det:
+    jet-slot tiles 1..25 all have kernel instances), hidden_single multiples of 64 up to 1024, hidden_double 16 or 32, up to 32
+    determinants."""
     import ctypes as C
     from deepsolid_amd import _lib
     lib = _lib.load()
@@ -142,7 +143,10 @@ def test_shape_limits_are_rejected_at_create():
 
     assert 'larger than 64' in err(n_up=65, n_dn=0)
     assert 'larger than 64' in err(n_up=40, n_dn=30, full_det=1)
-    assert 'jet-slot tiles' in err(n_up=30, n_dn=30)                      # N = 60: 12 slot tiles, no kernel instance
+    # N = 60 (12 jet-slot tiles), 81, 108, 128: every electron count whose matrices fit has kernel instances since round 4
+    # (1..25 slot tiles, csrc/ds_tiles.h) -- these descriptors pass every shape check and are refused only for their missing arrays
+    for n_up, n_dn in ((30, 30), (41, 40), (54, 54), (64, 64)):
+        assert 'null array' in err(n_up=n_up, n_dn=n_dn)
     assert 'hidden_single' in err(hidden_single=[256, 200, 256])
     assert 'hidden_single' in err(hidden_single=[2048, 256, 256])
     assert 'hidden_double' in err(hidden_double=[32, 24, 32])

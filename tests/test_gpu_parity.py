@@ -48,7 +48,7 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
 
 
-@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_2x1x1', 'bcc_li', 'graphene', 'diamond'])
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_2x1x1', 'bcc_li', 'graphene', 'diamond', 'bcc_li_333', 'graphene_331'])
 def test_ewald_vs_reference_vectors(name):
     fx, cell, klist, net_kw, params = load_case(name)
     from deepsolid_amd.ewaldsum import EwaldSum
@@ -173,7 +173,10 @@ SYM_CASES = ['lih_fcc', 'graphene_hex', 'bcc_li_bcc',      # feature lattices wi
              'lih_narrow', 'lih_mixed']                    # other layer widths, layers without residual connection
 
 
-@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'] + OPTION_CASES + SYM_CASES)
+LARGE_CASES = ['bcc_li_333', 'graphene_331']        # 81 and 108 electrons: 16 and 21 jet-slot tiles (instances added in round 4)
+
+
+@pytest.mark.parametrize('name', ['h2', 'lih', 'lih_twist', 'lih_2x1x1', 'bcc_li', 'bcc_li_twist', 'graphene', 'diamond'] + OPTION_CASES + SYM_CASES + LARGE_CASES)
 def test_logpsi_and_orbitals_vs_reference_vectors(name):
     from deepsolid_amd import network
     fx, cell, klist, net_kw, params = load_case(name)
