@@ -608,6 +608,13 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             else DS_TRM(6, 16, 4);
 #undef DS_TRM
 #undef DS_TRMF
+        } else if (n > 16 && n <= 64 && !s->det_valu) {
+            // any other size (odd n, or a slot tile of Y beyond the LDS): blocks of 16 electrons, two blocks of Y at a time
+            const size_t bbytes = (size_t)2 * 16 * 32 * 16 * sizeof(T) + (size_t)(S.P + 256) * sizeof(ds::Cx<T>);
+#define DS_TRB(KSMV) hipLaunchKernelGGL((ds::k_det_trace_blocked<T, KSMV>), dim3(S.K, (unsigned)Bc), dim3(256), bbytes, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp, \
+                                        c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS, L.dets_off[sp])
+            if (n <= 48) DS_TRB(24); else if (n <= 56) DS_TRB(28); else DS_TRB(32);
+#undef DS_TRB
         } else
         if (n <= 16) DS_TRACE(16, 16);
         else if (n <= 32) DS_TRACE(32, 8);

@@ -910,6 +910,125 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma_split(SysDev<T> S, c
 }
 
 // =====================================================================================
+// 5b-3. the same for ANY matrix size 16 < n <= 64 (odd sizes, and sizes whose slot tile of Y fits the LDS in neither of the modes
+//     above: n > 34 in float64): the electrons are cut into blocks of 16, and for every pair of blocks (a <= b) the two blocks
+//     Y[I_a][C_b] and Y[I_b][C_a] of one slot tile sit in the LDS together -- all that the pair sums of that block pair need.
+//     Nothing is computed twice; the rows of MOUT are read once per column block (n / 16 times, from the L2 after the first).
+//       loop order: block pairs outside (their two sets of A fragments stay in registers: four waves per workgroup, one per SIMD,
+//       for the 512-register budget), slot tiles inside; tr Y_d is collected per slot in the LDS by one owner thread per slot.
+// =====================================================================================
+template <typename T, int KSM>      // KSM >= ceil(2 n / 4) k-steps
+__global__ void __launch_bounds__(256) k_det_trace_blocked(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off,
+                                                           int ch, const T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
+                                                           T* __restrict__ TR, size_t tr_stride, size_t tr_off,
+                                                           T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+    typedef typename Acc4<T>::type acc_t;
+    constexpr int NTB = 2;                                 // a block of 16 electrons = 32 real columns = two accumulator tiles
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int kdet = blockIdx.x, w = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int P = S.P, n = S.det_n[ch], n2 = 2 * n, nks = (n2 + 3) / 4, R = (n + 15) / 16, ntile = P / 16;
+    T* Y0 = reinterpret_cast<T*>(smem_raw);               // [16 rows][32 columns][16 slots]: rows of I_a, columns of C_b
+    T* Y1 = Y0 + 16 * 32 * 16;                            //                                  rows of I_b, columns of C_a
+    Cx<T>* trl = reinterpret_cast<Cx<T>*>(Y1 + 16 * 32 * 16);     // [P] tr Y_d
+    Cx<T>* red = trl + P;                                 // [256]
+    const T* Iw = MINV + (size_t)w * minv_stride + minv_off + (size_t)kdet * n * n * 2;
+    const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
+    for (int p = tid; p < P; p += 256) trl[p] = Cx<T>(0, 0);
+    // A fragments of a column block: rows (e, ri2) of the real expansion of Minv^T, columns (m, ri); zero beyond the matrix
+    auto load_A = [&](T (&af)[NTB][KSM], int b) {
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KSM; ++ks) {
+                const int np = 32 * b + 16 * nt + lr, kp = 4 * ks + lq;
+                const int e = np >> 1, rip = np & 1, m = kp >> 1, ri = kp & 1;
+                T v = 0;
+                if (e < n && m < n) {
+                    v = Iw[(m * n + e) * 2 + (ri != rip ? 1 : 0)];
+                    if (ri != rip && rip == 0) v = -v;
+                }
+                af[nt][ks] = v;
+            }
+    };
+    // Y[I_a][C_.] of slot tile st with the A fragments of the column block: a wave takes rows wave, wave + 4, ...; the operands of
+    // its next row are requested before the products of the current one
+    auto block = [&](const T (&af)[NTB][KSM], int a, int st, T* Y) {
+        T bx[2][KSM];
+        auto load_row = [&](int u, int r) {
+            const int i = 16 * a + r;
+            const T* xp = Mw + ((size_t)st * n * n2 + (size_t)(i < n ? i : n - 1) * n2 + lq) * 16 + lr;
+#pragma unroll
+            for (int ks = 0; ks < KSM; ++ks) bx[u][ks] = (ks < nks && 4 * ks + lq < n2) ? xp[(size_t)(4 * ks) * 16] : T(0);
+        };
+        load_row(0, wave);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave + 4 * j;
+            if (j + 1 < 4) load_row((j + 1) & 1, r + 4);
+            if (16 * a + r < n) {
+                acc_t acc[NTB];
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt) acc[nt] = acc_t{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KSM; ++ks)
+                    if (ks < nks) {
+#pragma unroll
+                        for (int nt = 0; nt < NTB; ++nt) acc[nt] = mfma16(af[nt][ks], bx[j & 1][ks], acc[nt]);
+                    }
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Y[(r * 32 + 16 * nt + acc_row<T>(lane, q)) * 16 + lr] = acc[nt][q];
+            }
+        }
+    };
+    Cx<T> y2(0, 0);
+    const int d = tid & 15, g = tid >> 4;                 // pair sums: 16 thread groups x 16 slots
+    for (int a = 0; a < R; ++a)
+        for (int b = a; b < R; ++b) {
+            T afa[NTB][KSM], afb[NTB][KSM];
+            load_A(afb, b);
+            if (a != b) load_A(afa, a);
+            const T wgt = a == b ? T(1) : T(2);
+            for (int st = 0; st < ntile; ++st) {
+                block(afb, a, st, Y0);
+                if (a != b) block(afa, b, st, Y1);
+                __syncthreads();
+                const T* Yt = a == b ? Y0 : Y1;
+                const int slot = 16 * st + d;
+                if (slot >= 2 && slot < S.D) {
+                    for (int t = g; t < 256; t += 16) {
+                        const int r = t >> 4, c = t & 15;
+                        if (16 * a + r < n && 16 * b + c < n) {
+                            const Cx<T> yrc(Y0[(r * 32 + 2 * c) * 16 + d], Y0[(r * 32 + 2 * c + 1) * 16 + d]);
+                            const Cx<T> ycr(Yt[(c * 32 + 2 * r) * 16 + d], Yt[(c * 32 + 2 * r + 1) * 16 + d]);
+                            y2 = cx_fma(wgt * yrc, ycr, y2);
+                        }
+                    }
+                }
+                if (a == b && g == 0 && slot >= 1 && slot < S.D) {      // (one owner thread per slot: no atomics, a fixed order)
+                    Cx<T> t = trl[slot];
+                    for (int r = 0; r < 16 && 16 * a + r < n; ++r) t = t + Cx<T>(Y0[(r * 32 + 2 * r) * 16 + d], Y0[(r * 32 + 2 * r + 1) * 16 + d]);
+                    trl[slot] = t;
+                }
+                __syncthreads();
+            }
+        }
+    T* Tw = TR + (size_t)w * tr_stride + tr_off + (size_t)kdet * 2 * P;
+    for (int p = tid; p < S.D; p += 256)
+        if (p >= 1) { Tw[p] = trl[p].re; Tw[P + p] = trl[p].im; }
+    red[tid] = y2;
+    __syncthreads();
+    if (tid == 0) {
+        Cx<T> t(0, 0);
+        for (int u = 0; u < 256; ++u) t = t + red[u];
+        T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
+        dw[2] = t.re;
+        dw[3] = t.im;
+    }
+}
+
+// =====================================================================================
 // 5c. combine determinants (network.py:395-427 log-sum-exp) and assemble
 //        E_kin = -1/2 sum_k w_k [ lap log D_k + sum_d (d_d log D_k)^2 ],  w_k = D_k / sum D
 //     (equals the -1/2 sum_d [d_d^2 f + (d_d f)^2] of hamiltonian.py:59-68)
