@@ -253,11 +253,15 @@ def main():
         sync()
         if with_profile:
             sysd.profile(True, only='single_hidden')  # events + in-kernel clock probe on the hidden-layer kernel only
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(steps):
             loss, aux = total_energy(params, xb)
+        ev1.record()
         sync()
         dt_ = time.perf_counter() - t0
+        timed.gpu_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the library launches on: GPU time of the timed region
         if use_dist:
             t = torch.tensor([dt_], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -266,6 +270,7 @@ def main():
 
     log(f'system {args.system}: N={sum(cell.nelec)} batch/GPU={args.batch} world={world}; warm-up')
     dt, loss, aux = timed(x, args.steps, args.warmup, True)
+    gpu_ms_main = getattr(timed, 'gpu_ms', None)
     log('timed region done')
     prof = sysd.profile_read()
     clk_cycles, clk_ticks, clk_ghz = sysd.profile_clock()
@@ -329,6 +334,9 @@ def main():
     ndet = int(net_kw['determinants'])
     peak = PEAK_TFLOPS[dtype]
     n_hidden = len(net_kw['hidden_dims']) - 1
+    kms_pre = {k: v[0] for k, v in prof_all.items()}
+    lowrank = kms_pre.get('single_lr', 0.0) > 0           # the first hidden layer ran as k_layer1_lr
+    n_dense = n_hidden - (1 if lowrank else 0)             # launches of the dense hidden-layer kernel per step
     # algorithmic FLOPs per walker of the two MFMA kernels that can dominate a step
     f_layer = layer_flops(n_e, h1 + nch * h2, h1)                         # one hidden layer, all electrons
     f_orb = sum(2.0 * ns * (3 * n_e + 2) * h1 * (2 * ns * ndet) for ns in cell.nelec if ns)     # orbital head, both spins
@@ -340,9 +348,9 @@ def main():
         orb_name = orb_name.replace(f',{nb},{st},5>', f',3,{st},5>')
     # the roofline object describes the kernel with the largest share of the step
     ms_hidden, n_launch = prof['single_hidden']
-    flops_total = f_layer * args.batch * n_hidden * args.steps           # this rank, timed region
+    flops_total = f_layer * args.batch * n_dense * args.steps            # this rank, timed region (dense hidden layers only)
     achieved = flops_total / (ms_hidden * 1e-3) / 1e12 if ms_hidden > 0 else 0.0
-    hidden_obj = {'bound': 'mfma', 'kernel': hidden_name + ' (hidden one-electron layers: K=%d MFMA GEMM + fused tanh-jet epilogue)' % (h1 + nch * h2),
+    hidden_obj = {'bound': 'mfma', 'kernel': hidden_name + ' (dense hidden one-electron layer%s: K=%d MFMA GEMM + fused tanh-jet epilogue)' % ('s' if n_dense != 1 else '', h1 + nch * h2),
                   'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None, 'traffic_detail': None,
                   'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch, 'flops_per_walker_layer': f_layer,
                   'timing': 'HIP events inside the library around every launch of this kernel over the timed region',
@@ -360,6 +368,22 @@ def main():
                    'achieved': orb_ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': orb_ach / peak, 'traffic': None,
                    'flops_per_walker': f_orb, 'timing': 'HIP events, one extra profiled step outside the timed region',
                    'share_of_step': orb_ms / max(sum(kms.values()), 1e-9)}
+    lr_obj = None
+    if lowrank:
+        # first hidden layer on the low-rank form of the layer-0 output: its own (smaller) operation count -- per electron the
+        # weights C (Kh x (K0 + 2) x Nout), the products over the K0 + pair-mean rows, the recomputed residual rows
+        n_atoms = len(np.asarray(cell.original_cell.atom_coords()).reshape(-1, 3))
+        k0loc, k0sh = 4 * n_atoms + 4 * nch, 4 * n_atoms * nch
+        d_slots = 3 * n_e + 2
+        f_lr = n_e * (2.0 * h1 * h1 * (k0loc + k0sh + 2) + 2.0 * (k0loc + k0sh + nch * h2) * h1 * d_slots + 2.0 * k0loc * h1 * d_slots)
+        lr_ms = kms['single_lr']
+        lr_ach = f_lr * args.batch / (lr_ms * 1e-3) / 1e12
+        lr_obj = {'bound': 'mfma', 'kernel': hidden_name.replace('k_jet_gemm', 'k_layer1_lr').replace(',2>', ',NC,true>') +
+                  ' (first hidden layer on the rank-%d form of the layer-0 output)' % (k0loc + k0sh),
+                  'achieved': lr_ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': lr_ach / peak, 'traffic': None,
+                  'flops_per_walker': f_lr, 'dense_layer_flops_per_walker': f_layer,
+                  'timing': 'HIP events, one extra profiled step outside the timed region',
+                  'share_of_step': lr_ms / max(sum(kms.values()), 1e-9)}
     dominant = 'single_hidden' if kms.get('single_hidden', 0.0) >= orb_ms else 'orbital'
     roofline = hidden_obj if dominant == 'single_hidden' else orbital_obj
     if mcmc:
@@ -389,8 +413,11 @@ def main():
         'ranks_seen': ranks_seen,
         'energy_mean_ha': float(loss), 'energy_imag_ha': float(aux.imaginary), 'variance': float(aux.variance),
         'roofline': roofline,
-        'roofline_other_kernels': {'orbital_head': orbital_obj} if dominant == 'single_hidden' else {'hidden_layers': hidden_obj},
+        'roofline_other_kernels': dict(({'orbital_head': orbital_obj} if dominant == 'single_hidden' else {'hidden_layers': hidden_obj}),
+                                       **({'lowrank_layer': lr_obj} if lr_obj else {})),
         'kernel_ms_per_step': kms,     # from one extra untimed step
+        # evidence of GPU work that does not depend on an smi sample: HIP-event time of the timed region and the kernel sum of a step
+        'gpu_ms_timed_region': gpu_ms_main, 'kernel_ms_sum_per_step': sum(kms.values()),
         'mcmc': mcmc,
     }
     if other:

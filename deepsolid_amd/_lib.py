@@ -78,7 +78,7 @@ SIGNATURES = {
 }
 
 PROF_KINDS = ('features', 'm2_expand', 'two_layer', 'single_first', 'single_hidden', 'orbital', 'det_inverse',
-              'det_trace', 'combine', 'ewald', 'shared_term')
+              'det_trace', 'combine', 'ewald', 'shared_term', 'single_lr')
 
 _lib = None
 

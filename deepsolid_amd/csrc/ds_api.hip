@@ -477,7 +477,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             }
             {
             // ... then the N electron tiles with the fused epilogue
-            ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : DS_PROF_SINGLE_HIDDEN, st);
+            ProfScope ps(s, l == 0 ? DS_PROF_SINGLE_FIRST : ((lr_on && l == 1) ? DS_PROF_SINGLE_LR : DS_PROF_SINGLE_HIDDEN), st);
             // layer input tiles: G[gi], or (layer 0 in front of the low-rank layer 1) the XL buffer
             const T* Xin = (lr_on && l == 0) ? c.XL : c.G[gi];
             const size_t xws = (lr_on && l == 0) ? (size_t)S.N * K0loc * S.P : gws, xts = (lr_on && l == 0) ? (size_t)K0loc * S.P : gts;

@@ -254,15 +254,16 @@ int64_t ds_debug_stage(ds_system* sys, const void* params, const void* x, int64_
 #define DS_PROF_FEATURES 0
 #define DS_PROF_M2_EXPAND 1
 #define DS_PROF_TWO_LAYER 2
-#define DS_PROF_SINGLE_FIRST 3   /* k_jet_gemm of one-electron layer 0 (K = 4A + 8) */
-#define DS_PROF_SINGLE_HIDDEN 4  /* k_jet_gemm of the hidden one-electron layers (K = 256 + 64): the dominant kernel */
+#define DS_PROF_SINGLE_FIRST 3   /* one-electron layer 0 (K = 4A + 8): k_layer0_stats / k_jet_gemm<.,9> + k_layer0_means in front of the low-rank layer 1, else k_jet_gemm<.,1> */
+#define DS_PROF_SINGLE_HIDDEN 4  /* k_jet_gemm<.,2> of the dense hidden one-electron layers (K = 256 + 64): the dominant kernel */
 #define DS_PROF_ORBITAL 5        /* k_jet_gemm<.,5> of the orbital head (fused envelope x phase epilogue) */
 #define DS_PROF_DET_INVERSE 6
 #define DS_PROF_DET_TRACE 7
 #define DS_PROF_COMBINE 8
 #define DS_PROF_EWALD 9
 #define DS_PROF_SHARED_TERM 10    /* per-walker spin-mean term S = W_sh^T mean_i h_i (k_shared_term; layer 0: k_jet_gemm<.,0>) */
-#define DS_PROF_KINDS 11
+#define DS_PROF_SINGLE_LR 11     /* k_layer1_lr: the first hidden layer on the low-rank form of the layer-0 output */
+#define DS_PROF_KINDS 12
 int ds_profile_enable(ds_system* sys, int on);
 int ds_profile_read(ds_system* sys, double* ms_total, int64_t* launches);
 /* In-kernel clock probe of the dominant kernel (hidden one-electron layers), active while profiling is enabled for it: one
