@@ -561,6 +561,10 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const int n = S.det_n[sp];
         size_t sh = (size_t)n * 2 * n * sizeof(ds::Cx<T>) + 16;
         ProfScope ps(s, DS_PROF_DET_INVERSE, st);
+        // in-place Gauss-Jordan with one lane per matrix row where an instance exists (k_det_inv_wave; value = slot 0 of slot tile 0),
+        // else the LDS Gauss-Jordan kernel
+        if (s->no_lu_wave || !ds::launch_det_inv_wave<T>(n, dim3(S.K, (unsigned)Bc), st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp, 16, c.MINV, L.MINV,
+                                                         L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp], S.P))
         hipLaunchKernelGGL((ds::k_det_inverse<T>), dim3(S.K, (unsigned)Bc), dim3(64), sh, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp,
                            c.MINV, L.MINV, L.minv_off[sp], c.DETS, L.DETS, L.dets_off[sp], S.P, 16, 1, 1);   // value = slot 0 of slot tile 0
     }

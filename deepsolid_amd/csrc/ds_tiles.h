@@ -34,4 +34,10 @@ constexpr int tile_nb(int st, int elem_bytes) { return st <= 5 ? 4 : (st <= 10 ?
 // the table entry of a slot-tile count, or null (ds_api.hip; the parts are defined in ds_tiles_inst.hip)
 template <typename T> const TileOps<T>* tile_ops(int st_tiles);
 
+// k_det_inv_wave<T, NC> (ds_value.h; instances in ds_det_inst.hip: the unrolled elimination takes minutes to compile): inverse +
+// log det of the value matrices by in-place Gauss-Jordan with one lane per row.  Returns false when no instance covers n.
+template <typename T>
+bool launch_det_inv_wave(int n, dim3 grid, hipStream_t st, const SysDev<T>& S, const T* MOUT, size_t mout_stride, size_t mout_off, int ch, int es,
+                         T* MINV, size_t minv_stride, size_t minv_off, T* DETS, size_t dets_stride, size_t dets_off, int P);
+
 }  // namespace ds

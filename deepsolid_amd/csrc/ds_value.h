@@ -362,6 +362,98 @@ __global__ void __launch_bounds__(64) k_det_lu_wave(SysDev<T> S, const T* __rest
     }
 }
 
+// Inverse + log det by in-place Gauss-Jordan with one lane per matrix row (the forward-Laplacian chain: the determinant-trace
+// kernels need M^-1).  Same pivot rule as k_det_lu_wave (largest |a[r][K]| among the unused rows, lowest row on a tie, no row
+// exchange); at step K every other row is reduced and column K is overwritten by the new column of the inverse that belongs to
+// the pivot row p_K.  In the end lane r = p_i holds row i of the inverse with its columns in pivot order: Minv[i][p_K] = a[K].
+//   MOUT element (row, col, re/im) at ((row n + col) 2 + re/im) es  (es = 16: slot 0 of slot tile 0);  MINV [det][n][n][re,im].
+template <typename T, int NC, int K>
+__device__ __forceinline__ void gj_wave_step(Cx<T> (&a)[NC], LuState<T, NC>& st, int (&owners)[NC], int& mystep, int n, int lane) {
+    if (K >= n) return;
+    const bool free_row = !((st.used >> lane) & 1ull);
+    const T m2 = cx_abs2(a[K]);
+    T best = free_row ? m2 : T(-1);
+    best = best > T(-1) ? best : T(-1);
+    {
+        T o;
+        o = dpp_mov<0xB1>(best);  best = o > best ? o : best;
+        o = dpp_mov<0x4E>(best);  best = o > best ? o : best;
+        o = dpp_mov<0x141>(best); best = o > best ? o : best;
+        o = dpp_mov<0x140>(best); best = o > best ? o : best;
+        const T r0 = wave_bcast(best, 0), r1 = wave_bcast(best, 16), r2 = wave_bcast(best, 32), r3 = wave_bcast(best, 48);
+        const T m01 = r1 > r0 ? r1 : r0, m23 = r3 > r2 ? r3 : r2;
+        best = m23 > m01 ? m23 : m01;
+    }
+    const unsigned long long hit = __ballot(free_row && m2 == best);
+    int bi = hit ? __ffsll((long long)hit) - 1 : __ffsll((long long)(~st.used)) - 1;
+    const int owner = __builtin_amdgcn_readfirstlane(bi);
+    if (__popcll(~st.used & ((1ull << owner) - 1ull)) & 1) st.ph = Cx<T>(-st.ph.re, -st.ph.im);
+    st.used |= 1ull << owner;
+    owners[K] = owner;
+    mystep = lane == owner ? K : mystep;
+    const Cx<T> pk(wave_bcast(a[K].re, owner), wave_bcast(a[K].im, owner));
+    st.ph = st.ph * pk;
+    {
+        const T big = ds_abs(st.ph.re) > ds_abs(st.ph.im) ? ds_abs(st.ph.re) : ds_abs(st.ph.im);
+        const int e = big > T(0) ? ds_frexp_exp(big) : 0;
+        st.ph = Cx<T>(ds_ldexp(st.ph.re, -e), ds_ldexp(st.ph.im, -e));
+        st.esum += e;
+    }
+    const Cx<T> dinv = cx_inv(pk);
+    const bool piv = lane == owner;
+    // pivot row: a[m] / d (column K: 1 / d);  other rows: a[m] - f (a_p[m] / d) (column K: -f / d), f = a[K]
+    const Cx<T> f = a[K];
+    const Cx<T> nf(-f.re, -f.im);
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        if (m < n && m != K) {
+            const Cx<T> pm = Cx<T>(wave_bcast(a[m].re, owner), wave_bcast(a[m].im, owner)) * dinv;       // scaled pivot row (uniform)
+            const Cx<T> v = cx_fma(nf, pm, a[m]);
+            a[m].re = piv ? pm.re : v.re;
+            a[m].im = piv ? pm.im : v.im;
+        }
+    }
+    const Cx<T> ck = nf * dinv;
+    a[K].re = piv ? dinv.re : ck.re;
+    a[K].im = piv ? dinv.im : ck.im;
+}
+template <typename T, int NC, int... Ks>
+__device__ __forceinline__ void gj_wave_steps(std::integer_sequence<int, Ks...>, Cx<T> (&a)[NC], LuState<T, NC>& st, int (&owners)[NC], int& mystep,
+                                              int n, int lane) {
+    (gj_wave_step<T, NC, Ks>(a, st, owners, mystep, n, lane), ...);
+}
+template <typename T, int NC>
+__global__ void __launch_bounds__(64) k_det_inv_wave(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off, int ch, int es,
+                                                     T* __restrict__ MINV, size_t minv_stride, size_t minv_off,
+                                                     T* __restrict__ DETS, size_t dets_stride, size_t dets_off, int P) {
+    const int kdet = blockIdx.x, lane = threadIdx.x;
+    const long w = blockIdx.y;
+    const int n = S.det_n[ch];
+    const T* Mw = MOUT + (size_t)w * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P;
+    Cx<T> a[NC];
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+        if (lane < n && m < n) a[m] = Cx<T>(Mw[(size_t)((lane * n + m) * 2) * es], Mw[(size_t)((lane * n + m) * 2 + 1) * es]);
+        else a[m] = Cx<T>(T(0), T(0));
+    }
+    LuState<T, NC> st{n < 64 ? (~0ull << n) : 0ull, 0, Cx<T>(1, 0)};
+    int owners[NC], mystep = 0;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) owners[m] = 0;
+    gj_wave_steps<T, NC>(std::make_integer_sequence<int, NC>(), a, st, owners, mystep, n, lane);
+    if (lane < n) {
+        T* Iw = MINV + (size_t)w * minv_stride + minv_off + ((size_t)kdet * n + mystep) * n * 2;
+#pragma unroll
+        for (int m = 0; m < NC; ++m)
+            if (m < n) { Iw[2 * owners[m]] = a[m].re; Iw[2 * owners[m] + 1] = a[m].im; }
+    }
+    if (lane == 0) {
+        T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
+        dw[0] = T(0.5) * ds_log(cx_abs2(st.ph)) + T(st.esum) * T(0.69314718055994530942);
+        dw[1] = ds_atan2(st.ph.im, st.ph.re);
+    }
+}
+
 // M = phi * q (values).  PHI [group][elec in spin][ocols][PV], grid (n_s, groups), block 256
 template <typename T>
 __global__ void __launch_bounds__(256) k_orbital_epilogue_val(SysDev<T> S, const T* __restrict__ PHI, size_t phi_group_stride,

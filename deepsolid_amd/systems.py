@@ -47,7 +47,7 @@ def bcc_li(S=2, a0_ang=3.4268178940, nelec=None):
     prim = Cell(0.5 * a0 * np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]),
                 [('Li', [0.0, 0.0, 0.0])], spin=1)
     if nelec is None:
-        ne = 3 * int(S) ** 3
+        ne = 3 * abs(int(round(np.linalg.det(_smat(S)))))            # three electrons per atom, det S atoms
         nelec = (ne - ne // 2, ne // 2)
     return get_supercell(prim, _smat(S), nelec=nelec)
 
