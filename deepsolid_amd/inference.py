@@ -5,6 +5,7 @@
 This is SURVEY.md section 8 row f1: the smallest step from "kernel" to "usable VMC energy of a trained
 wavefunction".  Everything numeric runs in the HIP chain; this module is host bookkeeping only.
 """
+import logging
 import os
 
 import numpy as np
@@ -120,7 +121,9 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
     `check_nan` (cfg.debug.check_nan, process.py:303-318; on by default here: Adam updates in place, one NaN gradient would
     poison the parameters for good): a step with non-finite local energies / loss / gradient is discarded -- walkers,
     parameters and optimiser state keep their values, no CSV row is written for it (process.py:344), `rows` gets
-    ``{'step': t, 'rejected': True}``."""
+    ``{'step': t, 'rejected': True, 'pmove': ...}`` and a warning is logged like the reference's (process.py:316).  A walker with a
+    non-finite coordinate or non-finite parameters can never recover (the move is never accepted, the step never kept), so
+    after `max_rejected` = 20 rejections IN A ROW the loop raises instead of running to the end doing nothing."""
     from . import checkpoint
     gen = _rank_generator(key, data.device, t_init)
     batch = data.shape[0]
@@ -142,15 +145,22 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
     if writer:
         writer.__enter__()
     t_last = t_init + iterations - 1
+    n_rejected, max_rejected = 0, 20
     try:
         for t in range(t_init, t_init + iterations):
             data, params, opt_state, loss, aux, pmove, _ = step(t, data, params, opt_state, gen, width)
-            if loss is None:                                             # rejected step: nothing was updated, nothing is logged
+            if loss is None:                                             # rejected step: nothing was updated, no CSV row
                 rows.append({'step': t, 'rejected': True, 'pmove': float(pmove)})
+                n_rejected += 1
+                logging.warning('step %d: non-finite local energy / loss / gradient, step discarded (%d in a row)', t, n_rejected)
+                if n_rejected >= max_rejected:
+                    raise FloatingPointError(f'{n_rejected} consecutive training steps were rejected for non-finite values '
+                                             f'(last at step {t}): walkers or parameters are not finite')
             else:
                 row = {'step': t, 'energy': float(loss) / scale, 'variance': float(aux.variance) / scale ** 2,
                        'pmove': float(pmove), 'imaginary': float(aux.imaginary) / scale,
                        'kinetic': complex(aux.kinetic.mean().item()) / scale, 'ewald': float(aux.ewald.mean()) / scale}
+                n_rejected = 0
                 rows.append(row)
                 if writer:
                     writer.write(t, **row)

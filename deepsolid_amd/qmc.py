@@ -147,6 +147,20 @@ def importance_update(params, f, x1, key, lp_1, num_accepts, latvec, stddev=0.02
     return x_new, key, lp_new, num_accepts
 
 
+_HOST_GENERATORS = {}
+
+
+def _host_generator(gen):
+    """CPU generator paired with a device generator (keyed by the object): seeded from the device generator's seed the first
+    time, then advanced on the host only -- drawing a key costs no device round trip."""
+    g = _HOST_GENERATORS.get(id(gen))
+    if g is None or g[0] is not gen:
+        h = torch.Generator(device='cpu')
+        h.manual_seed(int(gen.initial_seed()) & (2 ** 63 - 1))
+        _HOST_GENERATORS[id(gen)] = g = (gen, h)
+    return g[1]
+
+
 def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms=None,
                    importance_sampling=None, one_electron_moves=False):
     if not isinstance(batch_slog_network, NetworkApply) or batch_slog_network.method_name != 'eval_slogdet':
@@ -188,7 +202,10 @@ def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms
                                     importance=imp, atoms=atoms)
         else:
             if isinstance(key, torch.Generator):
-                r = torch.randint(0, 2 ** 31 - 1, (2,), generator=key, device=key.device).tolist()
+                # the Philox key is drawn on the HOST (no device synchronisation per call): a CPU generator directly; a device
+                # generator through a CPU generator that is seeded from it once and travels with it
+                g = key if key.device.type == 'cpu' else _host_generator(key)
+                r = torch.randint(0, 2 ** 31 - 1, (2,), generator=g).tolist()
                 seed, off = (r[0] << 31) | r[1], 0
             else:
                 seed, off = int(key) * max(1, constants.world_size()) + constants.rank(), 0

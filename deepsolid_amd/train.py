@@ -137,7 +137,8 @@ def make_training_step(mcmc_step, val_and_grad, opt_update, check_nan=False):
     not finite is DISCARDED -- walkers, parameters and optimiser state keep their previous values and the step returns
     ``loss = aux_data = None``, like the reference's ``except AssertionError`` branch.  The decision is taken BEFORE the
     (in-place) optimiser update from quantities that are already identical on every rank (the all-reduced loss,
-    non-finite count and gradient), so all ranks skip together; it costs one device -> host read."""
+    non-finite count and gradient), so all ranks skip together; it costs two device -> host reads (the finiteness of loss and
+    gradient, the non-finite count of the local energies)."""
     packed = getattr(val_and_grad, 'value_and_grad_packed', None)
 
     def step(t, data, params, state, key, mcmc_width):

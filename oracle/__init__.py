@@ -15,11 +15,15 @@ Pinning status (see DESIGN.md "Oracle"):
     ``distance.py`` / ``supercell.py`` (``tests/golden/*.npz``, generator
     ``tools/make_golden.py``; jax.numpy replaced by a numpy stand-in because
     JAX is not installable here).
-  * kinetic energy: the reference has no golden numbers and its autodiff
-    runtime (jax.grad/jvp) is absent, so the `for`-mode restatement is pinned
-    indirectly: finite differences of the reference-executed forward, mode
-    equivalence for == hessian == partition == dim_batch, and the three
-    wavefunction properties the reference's test/test_network.py checks.
+  * kinetic energy and energy gradient: pinned DIRECTLY -- the reference's own
+    ``hamiltonian.py`` (``local_energy_seperate``, all four modes) and
+    ``train.py`` (``jax.value_and_grad(make_loss)``) are executed over its own
+    ``network.py`` under a torch-backed ``jax`` stand-in
+    (``tools/jax_torch_standin.py``); every fixture holds ``ke_ref`` / ``ew_ref``
+    (and ``grad_ref_*``), the oracle and the HIP chain are asserted against them
+    to 1e-9 Ha.  What is not pinned is XLA's own numerics (slogdet, erfc and the
+    autodiff underneath are numpy / scipy / torch here).  Finite differences of
+    the reference-executed forward and the mode equivalences stay as side checks.
   * Metropolis step: pinned by explicit-noise vectors (JAX threefry stream is
     not reproducible here; decisions are compared for supplied noise).
 """

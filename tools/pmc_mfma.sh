@@ -23,7 +23,7 @@ for c in ('SQ_INSTS_VALU_MFMA_MOPS_F64', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CY
             name = row['Kernel_Name'].split('(')[0].replace('void ', '')
             tot[name] += float(row['Counter_Value']); cnt[name] += 1
     for k in tot:
-        if k.startswith('ds::k_jet_gemm') or k.startswith('ds::k_shared') or k.startswith('ds::k_det_trace') or k.startswith('ds::k_two'):
+        if k.startswith('ds::k_jet_gemm') or k.startswith('ds::k_layer') or k.startswith('ds::k_shared') or k.startswith('ds::k_det_trace') or k.startswith('ds::k_two'):
             out.setdefault(k, {})[c + '_per_launch'] = tot[k] / cnt[k]
             out[k]['launches'] = cnt[k]
 print(json.dumps(out, indent=1))
