@@ -403,8 +403,10 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     // stage dumps, which show the dense path's buffers.
     const int K0loc = S.h1[0] + S.nch * S.h2[0], K0sh = S.nch * S.h1[0];
     const int lr_nc = std::max(2, (K0loc + K0sh + 4 + 15) / 16);      // column tiles of the per-electron weights C (instances: 2, 3, 4)
+    // (worth it when the weights C cost fewer products than the rows they replace: Kh / 4 k-steps of NB x NC tiles against
+    //  (Kh - K0 - 4) / 4 k-steps of NB x ST -- not for the one- or two-tile cells, N <= 10)
     const bool lr_on = s->use_lr && !dr && S.n_layers >= 2 && lr_nc <= 4 && S.h1[1] % 16 == 0 && (S.nch * S.h2[1]) % 4 == 0 &&
-                       3 * (K0loc + K0sh + 4) <= S.h1[1];
+                       3 * (K0loc + K0sh + 4) <= S.h1[1] && lr_nc * S.h1[1] < (S.h1[1] - K0loc - K0sh - 4) * ST;
     // 1. features
     {
         ProfScope ps(s, DS_PROF_FEATURES, st);

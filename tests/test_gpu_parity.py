@@ -319,9 +319,42 @@ def test_lowrank_first_hidden_layer_vs_dense_path(name, monkeypatch):
         out[flag] = torch.view_as_complex(sysd.local_energy(dp, x)[0]).cpu().numpy()
         prof = sysd.profile_read()
         sysd.profile(False)
-        assert (prof['single_lr'][1] > 0) == (flag is None), (flag, prof['single_lr'])      # the path under test really ran
+        lr_expected = flag is None and sum(cell.nelec) > 10            # (one- and two-tile cells keep the dense layers: no gain there)
+        assert (prof['single_lr'][1] > 0) == lr_expected, (flag, prof['single_lr'])      # the path under test really ran
         for b in range(nw):
             assert abs(out[flag][b] - fx['ke_ref'][b]) < 1e-9 * max(1.0, abs(fx['ke_ref'][b])), (flag, b, out[flag][b], fx['ke_ref'][b])
+    assert np.abs(out[None] - out['1']).max() < 1e-10 * max(1.0, np.abs(out['1']).max())
+
+
+@pytest.mark.parametrize('hidden_dims,nelec', [(((256, 32), (128, 16), (192, 32)), None),        # layer 1 without a residual connection
+                                               (((128, 16), (128, 16), (128, 16)), None),        # narrow streams
+                                               (((256, 32), (256, 32), (256, 32)), (24, 0))])    # one spin channel
+def test_lowrank_layer_other_architectures_vs_oracle(hidden_dims, nelec, monkeypatch):
+    """The low-rank first hidden layer on a 24-electron cell (the fixtures with other layer widths or one spin channel are 3- and
+    4-electron cells, which keep the dense layers): both paths against the forward-Laplacian oracle and against each other."""
+    from deepsolid_amd import systems
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('bcc_li', **({'nelec': nelec} if nelec else {}))
+    net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=hidden_dims)
+    params = make_test_params(91, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    dp = dev_params(params)
+    x64 = systems.synthetic_walkers(cell, 2, seed=9)
+    x = torch.as_tensor(x64, device='cuda')
+    ref = complex(ofl.stages(onet.params_to_torch(params), tt(x64[0]), klist, cell, net_kw)['ke'])
+    out = {}
+    for flag in (None, '1'):
+        if flag:
+            monkeypatch.setenv('DS_NO_LOWRANK', flag)
+        else:
+            monkeypatch.delenv('DS_NO_LOWRANK', raising=False)
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
+        sysd.profile(True)
+        out[flag] = torch.view_as_complex(sysd.local_energy(dp, x)[0]).cpu().numpy()
+        assert (sysd.profile_read()['single_lr'][1] > 0) == (flag is None)
+        sysd.profile(False)
+        assert abs(out[flag][0] - ref) < 1e-9 * max(1.0, abs(ref)), (flag, out[flag][0], ref)
     assert np.abs(out[None] - out['1']).max() < 1e-10 * max(1.0, np.abs(out['1']).max())
 
 
