@@ -97,10 +97,13 @@ struct ds_system {
     bool no_lu_wave = false;          // DS_NO_LU_WAVE: log det of 16 < n <= 64 by the Gauss-Jordan inverse kernel (as before round 3)
     bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
+    bool det_blocked = false;         // DS_DET_BLOCKED: k_det_trace_blocked for every n > 16 (A/B against the compile-time-size kernels)
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
+    bool use_wide = true;             // DS_NO_WIDE unset: the chunked kernels of ds_wide.h for more than 10 slot tiles where they are faster
+    bool wide_all = false;            // DS_WIDE_ALL: ... everywhere (tests, A/B runs)
     int dbg = 0;                      // DS_DBG (kernel development): 32 = phase stamps of one wave; 1 / 2 switch arithmetic off in a `make EXP=1` build only
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -365,7 +368,9 @@ inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz, int ST = 0) {
 }
 
 // k_m2_expand: feature splits (grid.z) so that a workgroup's pair jets take at most ~8 KB of LDS
+static int g_m2_split_override = 0;      // DS_M2_SPLIT (kernel development)
 template <typename T> inline unsigned m2_split(int K2, int N) {
+    if (g_m2_split_override > 0 && K2 % g_m2_split_override == 0) return (unsigned)g_m2_split_override;
     unsigned z = 1;
     while (z < 8 && K2 % (2 * z) == 0 && (size_t)(K2 / z) * 5 * N * sizeof(T) > 8192) z *= 2;
     return z;
@@ -397,6 +402,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     const ds::TileOps<T>* to = ds::tile_ops<T>(S.P / 16);
     if (!to) return fail("no kernel instance for %d slot tiles (N = %d electrons)", S.P / 16, S.N);
     const int NB = to->NB, ST = to->ST;
+    const bool wide = s->use_wide && to->gemm_wide != nullptr;      // wide slot ranges: 64-feature x 4/5-tile wave tiles in slot chunks (ds_wide.h)
     // Low-rank first hidden layer (k_layer1_lr): layer 0 reads its input tiles from their own buffer XL (layer 1 needs them again
     // while it overwrites G[0]) and does not write its dense output -- k_layer0_stats leaves (y, oL) per electron and the spin means
     // of the output (the input of layer 1's shared term), layer 1 recomputes its residual rows from the layer-0 input.  Off for the
@@ -456,6 +462,8 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         {
             dim3 block; unsigned gz;
             gemm_geom(Nout, NB, &block, &gz, ST);
+            dim3 wblock; unsigned wgz;                     // geometry of the wide kernels (NB = 4, four waves)
+            gemm_geom(Nout, 4, &wblock, &wgz, 6);
             const size_t gws = (size_t)S.N * S.ldk * S.P, gts = (size_t)S.ldk * S.P;
             T* Sl = (lr_on && l == 1) ? c.ZB + (size_t)Bc * S.h1[1] * S.P : c.ZB;      // this layer's shared term
             {
@@ -483,7 +491,10 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             // layer input tiles: G[gi], or (layer 0 in front of the low-rank layer 1) the XL buffer
             const T* Xin = (lr_on && l == 0) ? c.XL : c.G[gi];
             const size_t xws = (lr_on && l == 0) ? (size_t)S.N * K0loc * S.P : gws, xts = (lr_on && l == 0) ? (size_t)K0loc * S.P : gts;
-            const dim3 lgrid(S.N * gz, (unsigned)Bc, 1);
+            const dim3 lgrid(S.N * gz, (unsigned)Bc, 1), wgrid(S.N * wgz, (unsigned)Bc, 1);
+            auto layer_gemm = [&](int epi, const ds::GemmArgs<T>& g) {
+                if (!(wide && to->gemm_wide(epi, s->wide_all, wgrid, wblock, st, g))) to->gemm(epi, lgrid, block, st, g);
+            };
             ds::GemmArgs<T> ga{Xin, xws, xts, blk(s->i_wloc[l]), Kloc, nullptr, 0, nullptr, 0, S.N, c.G[gi ^ 1], gws, gts, Nout, S.P, c.ZB, blk(s->i_b[l]),
                                ds::OrbEpi<T>{}};
             if (lr_on && l == 1) {
@@ -491,7 +502,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 const ds::LrArgs<T> la{c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, c.MEAN[0], (size_t)K0sh * S.P, K0loc, K0sh,
                                        (const T*)s->lr_w0t, c.G[gi], gws, gts, blk(s->i_wloc[l]), Kh, S.nch * K2, c.G[gi ^ 1], gws, gts, Sl,
                                        Nout, S.P, S.N, c.YO, L.YO, blk(s->i_wloc[0]), c.ZB, s->dbg >> 8};
-                to->layer1_lr(lr_nc, res, lgrid, block, st, la);
+                if (!(wide && to->layer1_lr_wide(lr_nc, res, s->wide_all, wgrid, wblock, st, la))) to->layer1_lr(lr_nc, res, lgrid, block, st, la);
             } else if (lr_on && l == 0) {
                 // layer 0 without its dense output: (y, oL) per electron + the spin means of the output (ds_gemm.h).  One kernel when
                 // a wave holds all slot tiles of 16 features (k_layer0_stats) ...
@@ -501,7 +512,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 if (!one_kernel) {
                     // ... otherwise (y, oL) from the layer kernel with the output dropped (EPI 9), then the means per slot chunk (k_layer0_means)
                     ga.Z = c.YO; ga.zws = L.YO; ga.zts = (size_t)2 * Nout;
-                    to->gemm(9, lgrid, block, st, ga);
+                    layer_gemm(9, ga);
                     constexpr int STC = 5;
                     const unsigned nfb = (unsigned)((Nout + 63) / 64), nck = (unsigned)((S.P / 16 + STC - 1) / STC);
                     hipLaunchKernelGGL((ds::k_layer0_means<T, STC>), dim3(S.nch * nfb * nck, (unsigned)Bc), dim3(256), 0, st, S, c.XL,
@@ -510,9 +521,9 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             } else if (res) {
                 ga.oe.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }
-                to->gemm(2, lgrid, block, st, ga);
+                layer_gemm(2, ga);
             } else
-                to->gemm(1, lgrid, block, st, ga);
+                layer_gemm(1, ga);
             }
         }
         gi ^= 1;
@@ -553,8 +564,12 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 dim3 b3; unsigned gz3;
                 gemm_geom(OC, 3, &b3, &gz3);
                 to->gemm_orb3(dim3(ns * gz3, (unsigned)Bc, 1), b3, st, ga);
-            } else
-                to->gemm(5, dim3(ns * gz, (unsigned)Bc, 1), block, st, ga);
+            } else {
+                dim3 wb; unsigned wz;
+                gemm_geom(OC, 4, &wb, &wz, 6);
+                if (!(wide && to->gemm_wide(5, s->wide_all, dim3(ns * wz, (unsigned)Bc, 1), wb, st, ga)))
+                    to->gemm(5, dim3(ns * gz, (unsigned)Bc, 1), block, st, ga);
+            }
         }
     }
     if (stop == STOP_MOUT) return copy_out(dr, c.MOUT, L.MOUT * Bc, st);
@@ -590,7 +605,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const size_t ybytes8 = (size_t)n * 2 * n * 8 * sizeof(T) + 512 * sizeof(ds::Cx<T>);
         const bool sw8 = ybytes16 > 160 * 1024;
         const size_t ybytes = sw8 ? ybytes8 : ybytes16;
-        if ((2 * n) % 4 == 0 && ybytes <= 160 * 1024 && nt <= 6 && !s->det_valu) {
+        if ((2 * n) % 4 == 0 && ybytes <= 160 * 1024 && nt <= 6 && !s->det_valu && !(s->det_blocked && n > 16)) {
 #define DS_TRMF(NTV, SWV, NWV, NF) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV, NF>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp], (s->dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr)
@@ -1374,11 +1389,15 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     // environment switches are read here, once; the launch paths never call getenv
     if (const char* e = getenv("DS_STREAMS")) s->n_streams = atoi(e) == 2 ? 2 : 1;
     s->det_valu = getenv("DS_DET_VALU") != nullptr;
+    s->det_blocked = getenv("DS_DET_BLOCKED") != nullptr;
     s->det_half_slots = getenv("DS_DET_HALF_SLOTS") != nullptr;
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
+    s->use_wide = getenv("DS_NO_WIDE") == nullptr;
+    s->wide_all = getenv("DS_WIDE_ALL") != nullptr;
+    if (const char* e = getenv("DS_M2_SPLIT")) g_m2_split_override = atoi(e);
     // (grid.y carries the walker index: at most 65535 walkers per launch)
     if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::min<int64_t>(65535, std::max<int64_t>(1, atol(e)));
     if (s->n_streams == 2) {

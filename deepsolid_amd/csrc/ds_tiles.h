@@ -5,6 +5,7 @@
 //   NB = 4 for ST <= 5, 2 for ST <= 10, beyond that 1 (float64) / 2 (float32) with four waves per workgroup and one workgroup per CU.
 #pragma once
 #include "ds_gemm.h"
+#include "ds_wide.h"
 
 namespace ds {
 
@@ -26,6 +27,14 @@ template <typename T> struct TileOps {
     // k_layer0_stats<T, ST, nks> (ST <= 5, nks = 2, 3, 4): returns false when there is no such instance; or null
     bool (*layer0_stats)(int nks, dim3 grid, hipStream_t st, const SysDev<T>& S, const T* XL, size_t xl_ws, size_t xl_ts, const T* W0,
                          const T* S0, int Nout, int P, T* YO, T* MEAN1);
+    // wide slot ranges (ST > 10; ds_wide.h): the same products with 64-feature x <= 5-tile wave tiles walking the slot range in chunks,
+    // two waves per SIMD -- k_jet_gemm_wide<T, STC, epi> for epi = 1, 2, 5, 9 (grid / block for NB = 4: gemm_geom(Nout, 4, .., 5)) and
+    // k_layer1_lr_wide<T, STC, nc, res>; null for ST <= 10
+    // Both return false (nothing launched) when the chunked form is not the faster one for that kernel and element type -- measured:
+    // float64 all but the low-rank layer with three or more column tiles of C (its LDS block then leaves one workgroup per CU);
+    // float32 only layer 0 -- unless force is set (DS_WIDE_ALL=1: tests, A/B runs).
+    bool (*gemm_wide)(int epi, bool force, dim3 grid, dim3 block, hipStream_t st, const GemmArgs<T>& a);
+    bool (*layer1_lr_wide)(int nc, bool res, bool force, dim3 grid, dim3 block, hipStream_t st, const LrArgs<T>& a);
 };
 
 constexpr int DS_MAX_TILES = 25;

@@ -67,8 +67,39 @@ template <typename T, int NB, int ST> struct TileImpl {
         }
         return false;
     }
+    // chunk width of the wide kernels: 5 slot tiles in float32 (7 for the orbital head), 4 in float64 (five spill there)
+    static constexpr int STCW = sizeof(T) == 4 ? 5 : 4, STCO = sizeof(T) == 4 ? 7 : 4;
+    static bool gemm_wide(int epi, bool force, dim3 grid, dim3 block, hipStream_t st, const GemmArgs<T>& a) {
+        if constexpr (ST > 10) {
+            if (!force && sizeof(T) == 4 && epi != 1 && epi != 9) return false;
+#define DS_GW(STCV, E, LDS) hipLaunchKernelGGL((k_jet_gemm_wide<T, STCV, E>), grid, block, (LDS), st, a.X, a.xws, a.xts, a.W, a.K, a.n_tiles, a.Z, a.zws, a.zts, \
+                                               a.Nout, a.P, a.Sb, a.oe)
+            switch (epi) {
+                case 1: DS_GW(STCW, 1, 0); return true;
+                case 2: DS_GW(STCW, 2, (wide_stash_bytes<T, STCW>(block.x))); return true;
+                case 5: DS_GW(STCO, 5, 0); return true;
+                case 9: DS_GW(STCW, 9, 0); return true;
+                default: return false;
+            }
+#undef DS_GW
+        }
+        return false;
+    }
+    static bool layer1_lr_wide(int nc, bool res, bool force, dim3 grid, dim3 block, hipStream_t st, const LrArgs<T>& a) {
+        if constexpr (ST > 10) {
+            if (!force && (sizeof(T) == 4 || nc > 2)) return false;
+#define DS_LRW(NCV, RESV) hipLaunchKernelGGL((k_layer1_lr_wide<T, STCW, NCV, RESV>), grid, block, (lr_lds_bytes<T, 4, NCV>(block.x, a.Kh)), st, a)
+            if (nc <= 2) { if (res) DS_LRW(2, true); else DS_LRW(2, false); }
+            else if (nc == 3) { if (res) DS_LRW(3, true); else DS_LRW(3, false); }
+            else { if (res) DS_LRW(4, true); else DS_LRW(4, false); }
+#undef DS_LRW
+            return true;
+        }
+        return false;
+    }
     static const TileOps<T>* ops() {
-        static const TileOps<T> o = {NB, ST, &gemm, (ST <= 5 ? &gemm_orb3 : nullptr), &shared_term, &layer1_lr, (ST <= 5 ? &layer0_stats : nullptr)};
+        static const TileOps<T> o = {NB, ST, &gemm, (ST <= 5 ? &gemm_orb3 : nullptr), &shared_term, &layer1_lr, (ST <= 5 ? &layer0_stats : nullptr),
+                                      (ST > 10 ? &gemm_wide : nullptr), (ST > 10 ? &layer1_lr_wide : nullptr)};
         return &o;
     }
 };

@@ -377,6 +377,35 @@ def test_blocked_determinant_traces_vs_scalar_kernel(name, monkeypatch):
     assert abs(a[0] - fx['ke_ref'][0]) < 1e-9 * max(1.0, abs(fx['ke_ref'][0]))
 
 
+@pytest.mark.parametrize('name,dtype', [('bcc_li_333', torch.float64), ('graphene_331', torch.float64), ('diamond', torch.float32)])
+def test_wide_slot_range_kernels_vs_single_pass_kernels(name, dtype, monkeypatch):
+    """Beyond 10 jet-slot tiles the per-electron GEMMs exist twice: the single-pass kernels (a wave holds all slot tiles of its
+    features: one wave per SIMD) and the chunked kernels of csrc/ds_wide.h (64 features x 4 / 5 tiles, the slot range walked in
+    chunks, the Laplacian slot written last).  The library picks per kernel and element type what measured faster; DS_NO_WIDE=1 /
+    DS_WIDE_ALL=1 (read at system creation) force one family.  Both must give the same kinetic energy (float64: 1e-10 relative and
+    the reference-executed value; float32: the float32 tolerance of the walker against the float64 oracle)."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=dtype, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    x = torch.as_tensor(fx['x'][:1], dtype=dtype, device='cuda')
+    out = {}
+    for flag in ('DS_NO_WIDE', 'DS_WIDE_ALL'):
+        monkeypatch.delenv('DS_NO_WIDE', raising=False)
+        monkeypatch.delenv('DS_WIDE_ALL', raising=False)
+        monkeypatch.setenv(flag, '1')
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), dtype)
+        out[flag] = complex(torch.view_as_complex(sysd.local_energy(dp, x)[0].double())[0].cpu())
+    a, b = out['DS_NO_WIDE'], out['DS_WIDE_ALL']
+    if dtype == torch.float64:
+        assert abs(a - b) < 1e-10 * max(1.0, abs(a)), (a, b)
+        assert abs(b - fx['ke_ref'][0]) < 1e-9 * max(1.0, abs(fx['ke_ref'][0]))
+    else:
+        ref, loss = float32_budget(name, 1)
+        for v in (a, b):
+            assert abs(v - ref[0]) < float32_tolerance(loss, 0) * max(1.0, abs(ref[0])), (v, ref[0])
+
+
 @pytest.mark.parametrize('S,dtype', [((3, 3, 2), torch.float64), ((4, 3, 2), torch.float64), ((4, 3, 2), torch.float32)])
 def test_intermediate_electron_counts_vs_oracle(S, dtype):
     """Electron counts between the BASELINE sizes that had no kernel instances before round 4: bcc-Li 3x3x2 (54 e-, 11 jet-slot
