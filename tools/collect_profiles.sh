@@ -9,4 +9,5 @@ for k in bench graphene diamond value vjp; do f=$(find $G/${TAG}_$k -name "*kern
 cp $G/pmc_$TAG/summary.json $P/${TAG}_pmc_traffic.json
 cp $F/pmc_mfma.json $P/${TAG}_pmc_mfma.json
 cp $F/grad_bench.txt $P/${TAG}_grad_bench.txt
+for f in large_cells batch_sweep f32_stage_loss; do [ -f $F/$f.txt ] && cp $F/$f.txt $P/${TAG}_$f.txt; done
 ls -la $P | grep ${TAG}_

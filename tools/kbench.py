@@ -19,10 +19,12 @@ ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--check', type=int, default=2)
 ap.add_argument('--dtype', default='f64')
 ap.add_argument('--noprof', action='store_true')
-ap.add_argument('--S', type=int, default=0, help='supercell multiplier passed to the system builder (0: its default)')
+ap.add_argument('--S', default='0', help="supercell multiplier passed to the system builder: an integer, or 'a,b,c' for diag(a, b, c) (0: its default)")
 args = ap.parse_args()
 dtype = torch.float64 if args.dtype == 'f64' else torch.float32
-cell, klist = systems.build(args.system, **({'S': args.S} if args.S else {}))
+_S = [int(v) for v in str(args.S).split(',')]
+_S = (np.diag(_S) if len(_S) == 3 else _S[0])
+cell, klist = systems.build(args.system, **({'S': _S} if str(args.S) != '0' else {}))
 net_kw = dict(systems.DETNET_DEFAULTS)
 net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', dtype=dtype, **net_kw)
 params = net.init(0)
@@ -40,7 +42,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
 prof = sysd.profile_read()
 sysd.profile(False)
-print(f'{args.system}{" S=" + str(args.S) if args.S else ""} N={sum(cell.nelec)} B={args.batch} {args.dtype}: {dt * 1e3:.2f} ms/step = {args.batch / dt:.0f} evals/s')
+print(f'{args.system}{" S=" + str(args.S) if str(args.S) != "0" else ""} N={sum(cell.nelec)} B={args.batch} {args.dtype}: {dt * 1e3:.2f} ms/step = {args.batch / dt:.0f} evals/s')
 print('  ' + '  '.join(f'{k}={v[0] / args.steps:.2f}' for k, v in prof.items() if v[1]))
 if args.check:
     from oracle import forward_laplacian as ofl, network as onet, ewaldsum as oew

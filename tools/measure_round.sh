@@ -11,7 +11,6 @@ tail -c 900 $F/bench.json
 bash tools/profile_bench.sh ${TAG}_bench > $F/prof.txt 2>&1
 bash tools/pmc_traffic.sh $TAG > $F/pmc_traffic.txt 2>&1
 bash tools/pmc_mfma.sh $TAG > $F/pmc_mfma.json 2> $F/pmc_mfma.err
-python tools/gemm_timeline.py > $F/gemm_timeline.txt 2>&1
 bash tools/profile_cmd.sh ${TAG}_value tools/value_driver.py > /dev/null 2>&1
 bash tools/profile_cmd.sh ${TAG}_vjp tools/grad_bench.py bcc_li 4096 vjp > /dev/null 2>&1
 python tools/grad_bench.py bcc_li 4096 > $F/grad_bench.txt 2>&1
@@ -20,4 +19,9 @@ python bench.py --system graphene --batch 512 --steps 2 --no-cpu-baseline > $F/b
 python bench.py --system diamond --dtype f32 --batch 1024 --steps 2 --no-cpu-baseline > $F/bench_diamond.json 2>> $F/bench.err
 bash tools/profile_cmd.sh ${TAG}_graphene bench.py --system graphene --batch 512 --steps 2 --no-cpu-baseline --no-mcmc > /dev/null 2>&1
 bash tools/profile_cmd.sh ${TAG}_diamond bench.py --system diamond --dtype f32 --batch 1024 --steps 2 --no-cpu-baseline --no-mcmc > /dev/null 2>&1
+# cells between and beyond the BASELINE sizes (float64), the float32 stage-loss table, the forward / mcmc_step timings
+for a in "bcc_li 3,3,2 256" "bcc_li 4,3,2 256" "bcc_li 3 256" "graphene 3 128"; do set -- $a; python tools/kbench.py --system $1 --S $2 --batch $3 --steps 2 --check 0 2>&1 | grep -v "^/opt"; done > $F/large_cells.txt
+python tools/kbench.py --system diamond --batch 256 --steps 2 --check 1 2>&1 | grep -v "^/opt" >> $F/large_cells.txt
+for b in 256 512 1024 2048; do python tools/kbench.py --batch $b --steps 3 --check 0 2>&1 | grep -v "^/opt" | head -1; done > $F/batch_sweep.txt
+python tools/f32_stage_loss.py diamond 2>&1 | grep -v "^/opt" > $F/f32_stage_loss.txt
 ls -la $F
