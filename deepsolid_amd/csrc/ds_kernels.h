@@ -629,6 +629,22 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
     if (TILE_PF) load_tile(cur, 0);
     else { load_q(bc, 0); load_q(bn, 1); }
     int q = 0;
+    // pair terms of this thread (compile-time even n, full slot tiles): pi = g, g + NG, ... -> LDS offsets of Y[i][e] and Y[e][i]
+    // (measured: graphene's n = 24 instance 4.05 -> 3.79 ms per 512 walkers, bcc-Li's n = 12 instance 3.2 -> 3.75 ms per 4096 -- the offsets
+    //  cost it a wave of occupancy: used from n = 24 on)
+    constexpr bool FASTP = NFIX >= 24 && (NFIX % 2) == 0 && SW == 16;
+    constexpr int NPAIR = FASTP ? (NFIX / 2) * (NFIX + 1) : 1, NPT = FASTP ? (NPAIR + NG - 1) / NG : 1;
+    int poA[NPT], poB[NPT];
+    if constexpr (FASTP) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int pi = g + NG * k;
+            const int r = pi / (NFIX + 1), t = pi - r * (NFIX + 1);
+            const int i = t < NFIX - r ? r : NFIX - 1 - r, e = t < NFIX - r ? r + t : i + (t - (NFIX - r));
+            poA[k] = pi < NPAIR ? (i * n2 + 2 * e) * SW + d : -1;
+            poB[k] = (e * n2 + 2 * i) * SW + d;
+        }
+    }
     if (stamp) c_setup = clock64() - c_begin;
     for (int sp = 0; sp < nsp; ++sp) {
         const int st = sp / (16 / SW), half = sp % (16 / SW);
@@ -686,6 +702,33 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
         if (stamp) { const long long c = clock64(); c_bar1 += c - c_t; c_t = c; }
         const int slot = 16 * st + SW * half + d;
         const bool live = slot >= 1 && slot < S.D;
+        if constexpr (FASTP) {
+            // compile-time matrix size: the (i, e) of a thread's pair terms were worked out before the tile loop; tr Y_d is summed by
+            // ONE thread per slot (group 0) straight from the diagonal -- no reduction buffer, one barrier less per tile
+#pragma unroll
+            for (int k = 0; k < NPT; ++k)
+                if (poA[k] >= 0 && slot >= 2) {
+                    const Cx<T> yie(Y[poA[k]], Y[poA[k] + SW]), yei(Y[poB[k]], Y[poB[k] + SW]);
+                    y2 = cx_fma((poA[k] == poB[k] ? T(1) : T(2)) * yie, yei, y2);
+                }
+            if (g == 0 && live) {
+                Cx<T> t(0, 0);
+#pragma unroll
+                for (int i = 0; i < (NFIX > 0 ? NFIX : 1); ++i) t = t + Cx<T>(Y[((size_t)i * n2 + 2 * i) * SW + d], Y[((size_t)i * n2 + 2 * i + 1) * SW + d]);
+                Tw[slot] = t.re;
+                Tw[P + slot] = t.im;
+            }
+            if (stamp) { const long long c = clock64(); c_pairs += c - c_t; c_t = c; }
+            __syncthreads();
+            if (stamp) { const long long c = clock64(); c_bar2 += c - c_t; c_t = c; }
+            if (TILE_PF) {
+#pragma unroll
+                for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+                    for (int ks = 0; ks < KSMAX; ++ks) cur[rr][ks] = nxt[rr][ks];
+            }
+            continue;
+        }
         Cx<T> trc(0, 0);
         // sum_{i,e} Y[i][e] Y[e][i] = sum_i Y[i][i]^2 + 2 sum_{i<e} Y[i][e] Y[e][i]: upper triangle only.  Rows r and
         // n-1-r together hold n+1 entries (n even); odd n walks the full square.
