@@ -10,11 +10,13 @@
 set -u
 cd "$(dirname "$0")/.."
 RTDIR=$(dirname "$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)")
-FLAGS="-O1 -g -std=c++17 --offload-arch=gfx950 -fPIC -shared -Wno-unused-result -Wno-option-ignored -shared-libsan -fno-omit-frame-pointer"
+SAN="-O1 -g -Wno-option-ignored -shared-libsan -fno-omit-frame-pointer"
+J=$(nproc)
 case "${1:-run}" in
 build)
-    /opt/rocm/bin/hipcc $FLAGS -fsanitize=address,undefined deepsolid_amd/csrc/ds_api.hip -o deepsolid_amd/libdeepsolid_hip_asan.so
-    /opt/rocm/bin/hipcc $FLAGS -fsanitize=undefined -fno-sanitize-recover=undefined deepsolid_amd/csrc/ds_api.hip -o deepsolid_amd/libdeepsolid_hip_ubsan.so
+    # (the library is twelve objects since round 4: the Makefile builds them with the sanitizer flags into their own directories)
+    make -j$J -C deepsolid_amd/csrc OUT=../libdeepsolid_hip_asan.so OBJDIR=build_asan EXTRA="$SAN -fsanitize=address,undefined"
+    make -j$J -C deepsolid_amd/csrc OUT=../libdeepsolid_hip_ubsan.so OBJDIR=build_ubsan EXTRA="$SAN -fsanitize=undefined -fno-sanitize-recover=undefined"
     ;;
 run-cpu)
     export DEEPSOLID_HIP_LIB=$PWD/deepsolid_amd/libdeepsolid_hip_asan.so LD_PRELOAD=$RTDIR/libclang_rt.asan-x86_64.so
