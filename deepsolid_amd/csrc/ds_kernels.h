@@ -385,13 +385,16 @@ __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __rest
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Cx<T>* aug = reinterpret_cast<Cx<T>*>(smem_raw);   // [n][2n]
     const int kdet = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
-    const int n = S.det_n[sp], n2 = 2 * n;      // sp = determinant channel
+    // MINV == nullptr: log det only (value chain, matrices beyond the register LU kernels): plain LU on the n x n matrix -- no identity
+    // block, only the rows below the pivot are reduced (a sixth of the Gauss-Jordan work)
+    const bool lu_only = MINV == nullptr;
+    const int n = S.det_n[sp], n2 = lu_only ? n : 2 * n;      // sp = determinant channel
     int* piv_p = reinterpret_cast<int*>(aug + n * n2);  // all LDS in the one dynamic region (16-B aligned base)
     const T* Mw = MOUT + (size_t)(w / cols_per_group) * mout_stride + mout_off + (size_t)kdet * n * n * 2 * P + w % cols_per_group;
     for (int idx = lane; idx < n * n; idx += 64) {
         const int r = idx / n, c = idx % n;
         aug[r * n2 + c] = Cx<T>(Mw[(size_t)(idx * 2) * es], Mw[(size_t)(idx * 2 + 1) * es]);
-        aug[r * n2 + n + c] = Cx<T>(r == c ? T(1) : T(0), T(0));
+        if (!lu_only) aug[r * n2 + n + c] = Cx<T>(r == c ? T(1) : T(0), T(0));
     }
     __syncthreads();
     T logabs = 0;
@@ -425,7 +428,16 @@ __global__ void __launch_bounds__(64) k_det_inverse(SysDev<T> S, const T* __rest
         __syncthreads();
         for (int c = lane; c < n2; c += 64) aug[j * n2 + c] = aug[j * n2 + c] * dinv;
         __syncthreads();
-        // eliminate column j from every other row
+        // eliminate column j from every other row (log det only: from the rows below, columns to the right)
+        if (lu_only) {
+            const int m = n - 1 - j;
+            for (int idx = lane; idx < m * m; idx += 64) {
+                const int r = j + 1 + idx / m, c = j + 1 + idx % m;
+                aug[r * n2 + c] = aug[r * n2 + c] - aug[r * n2 + j] * aug[j * n2 + c];
+            }
+            __syncthreads();
+            continue;
+        }
         for (int idx = lane; idx < n * n2; idx += 64) {
             const int r = idx / n2, c = idx % n2;
             if (r == j || c == j) continue;
