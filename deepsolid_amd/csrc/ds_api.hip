@@ -95,6 +95,7 @@ struct ds_system {
     // kernels of the other; the side streams fork from / join the caller's stream with events
     int n_streams = 1;
     bool no_lu_wave = false;          // DS_NO_LU_WAVE: log det of 16 < n <= 64 by the Gauss-Jordan inverse kernel (as before round 3)
+    int val_nb = 0;                   // DS_VAL_NB = 1 / 2 / 4: one wave-tile width for the value chain's GEMMs (default: by workgroup count)
     bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
     bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
     bool det_blocked = false;         // DS_DET_BLOCKED: k_det_trace_blocked for every n > 16 (A/B against the compile-time-size kernels)
@@ -366,6 +367,21 @@ inline void gemm_geom(int Nout, int NB, dim3* block, unsigned* gz, int ST = 0) {
     *block = dim3(wpb * 64);
     *gz = (unsigned)((nw + wpb - 1) / wpb);
 }
+
+// Value chain: the wave tile of a GEMM launch follows the number of workgroups it would have with 64-feature waves.  A 4096-walker
+// batch (52 groups of 80 walkers x 24 electrons) fills the chip's 512 four-wave slots 2.4 times over; the 512 walkers of a GPU's
+// share of a split batch make 168 workgroups -- each a serial chain of K/4 x 20 MFMAs on a SIMD of its own.  32- / 16-feature waves
+// in four-wave workgroups: 2 x / 4 x the workgroups, chains a half / a quarter as long; the same products in the same order
+// (bit-identical results).  DS_VAL_NB forces one width (tests, measurements).
+inline int val_nb(int forced, int64_t wgs64) { return forced ? forced : (wgs64 >= 1024 ? 4 : (wgs64 >= 448 ? 2 : 1)); }
+inline void val_geom(int Nout, int NB, dim3* block, unsigned* gz) {
+    if (NB >= 3) { gemm_geom(Nout, NB, block, gz); return; }
+    *block = dim3(256);
+    *gz = (unsigned)((Nout + 64 * NB - 1) / (64 * NB));
+}
+
+// k_m2_combine_val: rows per workgroup (grid.z chunks inside one partner spin)
+inline int m2_rc(int K2) { return K2 % 16 == 0 ? 16 : K2; }
 
 // k_m2_expand: feature splits (grid.z) so that a workgroup's pair jets take at most ~8 KB of LDS
 static int g_m2_split_override = 0;      // DS_M2_SPLIT (kernel development)
@@ -720,7 +736,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         // partner means of the pair stream -> rows [Kh, Kh + nch*K2): layer 0 from H2 itself; later layers from the segment sums
         // the previous pair layer left behind (no second pass over H2) when every spin has >= 8 electrons
         if (l > 0 && l <= S.n_double && fuse_means)
-            hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng), dim3(256), (size_t)S.nch * K2 * PV * sizeof(T), st, S, vb.PARTM, K2, Gin, Kh);
+            hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng, (unsigned)(S.nch * K2 / m2_rc(K2))), dim3(256), (size_t)m2_rc(K2) * PV * sizeof(T), st, S, vb.PARTM, K2, Gin, Kh, m2_rc(K2));
         else
             hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, Hin, K2, Gin, Kh);
         if (l < S.n_double) {
@@ -743,6 +759,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         if (Kh == Nout && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         dim3 block; unsigned gz;
         gemm_geom(Nout, 4, &block, &gz);
+        const int nbh = val_nb(s->val_nb, (int64_t)S.N * ng * gz);
         if (l == 0)
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 7>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
                                (const T*)nullptr, 0, vb.MEAN0, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, (size_t)0, Nout, PV,
@@ -754,21 +771,31 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
             // one tile per 80-walker group: with 64-feature waves a 4096-walker batch is 208 waves on 1024 SIMDs, each a serial chain
             // of Ksh/4 x 20 MFMAs (75 us at Ksh = 512).  16-feature waves in 64-feature workgroups: four times the waves on four
             // times the CUs, a quarter of the chain each (same products in the same order: bit-identical)
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, 1, 5, 7>), dim3(1, (unsigned)ng, (unsigned)(Nout / 64)), dim3(256), 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
-                               (const T*)nullptr, 0, vb.MEANS, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, (size_t)0, Nout, PV,
-                               (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
+            // few groups: 16-walker column blocks as well (grid.x; operand and output advance by 16 columns per block), five times
+            // the waves with a fifth of the chain
+            if (nbh < 4 && Ksh % 16 == 0)
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, 1, 1, 7>), dim3(PV / 16, (unsigned)ng, (unsigned)(Nout / 64)), dim3(256), 0, st, (const T*)nullptr, (size_t)0, (size_t)16,
+                                   (const T*)nullptr, 0, vb.MEANS, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, (size_t)16, Nout, PV,
+                                   (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
+            else
+                hipLaunchKernelGGL((ds::k_jet_gemm<T, 1, 5, 7>), dim3(1, (unsigned)ng, (unsigned)(Nout / 64)), dim3(256), 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
+                                   (const T*)nullptr, 0, vb.MEANS, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, (size_t)0, Nout, PV,
+                                   (const T*)nullptr, blk(s->i_b[l]), ds::OrbEpi<T>{});
         }
-        if (Kh == Nout)
-            hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 4>), dim3(S.N, (unsigned)ng, gz), block, (ds::gemm_stash_bytes<T, 4, 5>(block.x)), st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
-                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, gws, gts, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
-        else
+#define DS_VHID(NBV) { dim3 hb; unsigned hz; val_geom(Nout, NBV, &hb, &hz); \
+            hipLaunchKernelGGL((ds::k_jet_gemm<T, NBV, 5, 4>), dim3(S.N, (unsigned)ng, hz), hb, (ds::gemm_stash_bytes<T, NBV, 5>(hb.x)), st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc, \
+                               (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, gws, gts, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{}); }
+        if (Kh == Nout) {
+            if (nbh == 4) DS_VHID(4) else if (nbh == 2) DS_VHID(2) else DS_VHID(1)
+        } else
+#undef DS_VHID
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 3>), dim3(S.N, (unsigned)ng, gz), block, 0, st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
                                (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, gws, gts, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
     }
     T* Gl = vb.Gl[S.n_layers];
     const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
     if (s->use_last) {
-        if (fuse_means) hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng), dim3(256), (size_t)S.nch * K2l * PV * sizeof(T), st, S, vb.PARTM, K2l, Gl, Kl);
+        if (fuse_means) hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng, (unsigned)(S.nch * K2l / m2_rc(K2l))), dim3(256), (size_t)m2_rc(K2l) * PV * sizeof(T), st, S, vb.PARTM, K2l, Gl, Kl, m2_rc(K2l));
         else hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, vb.H2l[S.n_double], K2l, Gl, Kl);
     }
     for (int sp = 0; sp < S.nch; ++sp) {
@@ -799,7 +826,10 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
                            OC, PV, s->use_last ? (const T*)Sorb : (const T*)nullptr, (const T*)nullptr, oe)
         // 192 columns would be three 64-column waves per workgroup: 48-column waves give four balanced ones (as in the
         // forward-Laplacian chain's orbital head): 131 -> 94 us per 4096 bcc-Li walkers
-        if (OC % 256 != 0 && OC % 192 == 0) DS_VORB(3, dim3(256), (unsigned)(OC / 192));
+        const bool w48 = OC % 256 != 0 && OC % 192 == 0;
+        const int nbo = val_nb(s->val_nb, (int64_t)ns * ng * (w48 ? OC / 192 : ogz));
+        if (nbo < 4) DS_VORB(1, dim3(256), (unsigned)((OC + 63) / 64));
+        else if (w48) DS_VORB(3, dim3(256), (unsigned)(OC / 192));
         else DS_VORB(4, oblock, ogz);
 #undef DS_VORB
     }
@@ -808,11 +838,16 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         for (int sp = 0; sp < S.n_detch; ++sp) {
             const int n = S.det_n[sp];
             if (!vb.MINV && n <= 16) {              // log det only: register LU, four lanes per matrix
-                const dim3 lgrid(S.K, (unsigned)((Bc + 63) / 64));
-#define DS_LU(RV) hipLaunchKernelGGL((ds::k_det_lu_val<T, RV>), lgrid, dim3(256), 0, st, S, MOUT, L.MOUT, L.mout_off[sp], sp, (long)Bc, DETS, dstride, \
-                                     s->ws.dets_off[sp])
+                // both determinant channels in one launch when they take the same instance (a channel alone is 64 workgroups
+                // per 512 walkers -- a latency chain on a quarter of the chip)
+                auto rof = [](int m) { return m <= 4 ? 1 : (m <= 8 ? 2 : (m <= 12 ? 3 : 4)); };
+                const bool both = sp + 1 < S.n_detch && S.det_n[sp + 1] <= 16 && rof(S.det_n[sp + 1]) == rof(n);
+                const dim3 lgrid(S.K, (unsigned)((Bc + 63) / 64), both ? 2 : 1);
+                const ds::DetOff2 off{{L.mout_off[sp], both ? L.mout_off[sp + 1] : 0}, {s->ws.dets_off[sp], both ? s->ws.dets_off[sp + 1] : 0}};
+#define DS_LU(RV) hipLaunchKernelGGL((ds::k_det_lu_val<T, RV>), lgrid, dim3(256), 0, st, S, MOUT, L.MOUT, off, sp, (long)Bc, DETS, dstride)
                 if (n <= 4) DS_LU(1); else if (n <= 8) DS_LU(2); else if (n <= 12) DS_LU(3); else DS_LU(4);
 #undef DS_LU
+                if (both) ++sp;
                 continue;
             }
             if (!vb.MINV && n <= (sizeof(T) == 4 ? 64 : 48) && !s->no_lu_wave) {      // log det only, one lane per row (float64: 48 x 2 x 2 VGPRs per row)
@@ -1392,6 +1427,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     s->det_blocked = getenv("DS_DET_BLOCKED") != nullptr;
     s->det_half_slots = getenv("DS_DET_HALF_SLOTS") != nullptr;
     s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
+    if (const char* e = getenv("DS_VAL_NB")) { const int v = atoi(e); s->val_nb = (v == 1 || v == 2 || v == 4) ? v : 0; }
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);

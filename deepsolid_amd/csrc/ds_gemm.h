@@ -12,6 +12,13 @@
 
 #include "ds_kernels.h"
 
+#ifndef DS_SADD
+#define DS_SADD 1
+#endif
+#ifndef DS_SADD_NSF
+#define DS_SADD_NSF 2
+#endif
+
 namespace ds {
 
 // Orbital-head weights are packed so that the MFMA accumulator hands one lane the pairs (Re, Im) of
@@ -156,6 +163,86 @@ __device__ __forceinline__ void layer_epilogue(typename Acc4<T>::type (&acc)[NB]
     }
 }
 
+// The residual layer epilogue (EPI 2) of the 64-feature x 5-tile wave tile with the shared term S ADDED HERE instead of loaded into the
+// accumulators before the first MFMA (where 80 loads per lane sit in front of the products): the rows of S of the first NSF row groups
+// and the value-tile entries of all groups were requested during the last k-steps into the operand ring's dying registers (sfull, s0),
+// the other groups' rows follow two groups ahead like the residual rows.
+template <typename T, int NB, int ST, int NA, int NSF>
+__device__ __forceinline__ void layer_epilogue_sadd(typename Acc4<T>::type (&acc)[NB][ST], const T* __restrict__ Gi, T* __restrict__ Go,
+                                                    const T* stash, int n0, int lane, int P, const T* __restrict__ Sp, T (&sfull)[NSF][ST],
+                                                    T (&s0)[NB * 4]) {
+    const int lr = lane & 15;
+    const T rs2 = T(0.70710678118654752440);
+    constexpr int NQ = NB * 4, NQL = NA * 4, NQG = NQ - NQL, DEPTH = NQG < 2 ? NQG : 2, DS = 2;
+    T hq[DEPTH > 0 ? DEPTH : 1][ST], sq[DS][ST];
+    auto fetch = [&](int q, int slot) {
+        const int n = n0 + 16 * (q >> 2) + acc_row<T>(lane, q & 3);
+#pragma unroll
+        for (int s = 0; s < ST; ++s) hq[slot][s] = Gi[n * P + 16 * s];
+    };
+    auto fetch_s = [&](int q, int slot) {                      // (tile 0 of the row is already in s0[q])
+        const int n = n0 + 16 * (q >> 2) + acc_row<T>(lane, q & 3);
+#pragma unroll
+        for (int s = 1; s < ST; ++s) sq[slot][s] = Sp[n * P + 16 * s];
+    };
+#pragma unroll
+    for (int g = 0; g < DS; ++g)
+        if (NSF + g < NQ) fetch_s(NSF + g, g);
+#pragma unroll
+    for (int g = 0; g < DEPTH; ++g) fetch(NQL + g, g);
+    if (NA > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    T zsel = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const T v = row16_bcast<0>(acc[q >> 2][0][q & 3] + s0[q]);
+        zsel = lr == q ? v : zsel;
+    }
+    const T yall = ds_tanh(zsel);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int a = q >> 2, r = q & 3;
+        const int n = n0 + 16 * a + acc_row<T>(lane, r);
+        T z[ST], hv[ST];
+        z[0] = acc[a][0][r] + s0[q];
+        if (q < NSF) {
+#pragma unroll
+            for (int s = 1; s < ST; ++s) z[s] = acc[a][s][r] + sfull[q][s];
+        } else {
+            const int slot = (q - NSF) % DS;
+#pragma unroll
+            for (int s = 1; s < ST; ++s) z[s] = acc[a][s][r] + sq[slot][s];
+            if (q + DS < NQ) fetch_s(q + DS, slot);
+        }
+        if (q < NQL) {
+            const int rr = 16 * a + acc_row<T>(lane, r);
+#pragma unroll
+            for (int s = 0; s < ST; ++s) hv[s] = stash[((rr >> 2) * ST + s) * 64 + ((rr & 3) << 4) + lr];
+        } else {
+            const int slot = (q - NQL) % (DEPTH > 0 ? DEPTH : 1);
+#pragma unroll
+            for (int s = 0; s < ST; ++s) hv[s] = hq[slot][s];
+            if (q + DEPTH < NQ) fetch(q + DEPTH, slot);
+        }
+        T ss = 0;
+#pragma unroll
+        for (int s = 0; s < ST; ++s)
+            if (16 * s + lr >= 2) ss += z[s] * z[s];
+        ss = row16_sum(ss);
+        const T zL = row16_bcast<1>(z[0]);
+        const T y = row16_bcast_dyn<NQ>(yall, q), d1 = 1 - y * y, d2 = -2 * y * d1;
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+            T o = d1 * z[s];
+            if (s == 0) { if (lr == 0) o = y; else if (lr == 1) o = d1 * zL + d2 * ss; }
+            o = (hv[s] + o) * rs2;
+            __builtin_nontemporal_store(o, &Go[n * P + 16 * s]);
+        }
+    }
+}
+
 // One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x up to 1024/NB
 // output features (grid.z walks further column blocks); every wave owns 16*NB features.  Tiles 0..n_tiles-1 use (X, W, K);
 // the optional extra tile (blockIdx.x == n_tiles) uses (X2, W2, K2): the shared spin-mean term.
@@ -214,7 +301,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         Wp = W;
         nks = K / 4;
     } else {
-        Xp = X2 + (size_t)w * x2_walker_stride;
+        // (tiles beyond n_tiles of a shared-operand launch are COLUMN blocks of the one operand: x_tile_stride = columns per block)
+        Xp = X2 + (size_t)w * x2_walker_stride + (size_t)(tile - n_tiles) * x_tile_stride;
         Wp = W2;
         nks = K2 / 4;
     }
@@ -226,7 +314,11 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
     T* stash = reinterpret_cast<T*>(gemm_smem) + (size_t)wave * (NA * 4 * ST * 64);
     acc_t acc[NB][ST];
-    if (LAYER && !(EPI == 2 && DS_EXP(oe.dbg & 2))) {
+    // (the dense 24-electron instance adds S in its epilogue: layer_epilogue_sadd)
+    constexpr bool SADD = EPI == 2 && NB == 4 && ST == 5 && sizeof(T) == 8 && DS_SADD;
+    constexpr int NSF = DS_SADD_NSF;
+    T sfull[SADD ? NSF : 1][ST], s0[NB * 4];
+    if (LAYER && !SADD && !(EPI == 2 && DS_EXP(oe.dbg & 2))) {
         // z = W x + (S + b): the accumulators start at the shared spin-mean term, which already carries the bias
         // (EPI = 6 / 7 below, k_shared_term); these loads overlap the first operand loads
         const T* Sp0 = Sb + (size_t)w * Nout * P + lr;
@@ -286,8 +378,28 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { step(u, ks + u); load_set(u); }
             }
+            if constexpr (SADD) {
+                // the last four k-steps reload nothing: the rows of S go into the registers of the sets as they die
+                // (5 full row groups = 25 values + the value-tile entries of the other 11 groups = 36 = the ring)
+                const T* Sp0 = Sb + (size_t)w * Nout * P + lr;
+                auto srow = [&](int q) { return Sp0 + (size_t)(n0 + 16 * (q >> 2) + acc_row<T>(lane, q & 3)) * P; };
+                auto lfull = [&](int q) {
+                    const T* p = srow(q);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) step(u, ks + u);
+                    for (int s = 0; s < ST; ++s) sfull[q][s] = p[16 * s];
+                    s0[q] = sfull[q][0];
+                };
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    step(u, ks + u);
+#pragma unroll
+                    for (int q = 0; q < NB * 4; ++q)
+                        if ((q & 3) == u) { if (q < NSF) lfull(q); else s0[q] = srow(q)[0]; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) step(u, ks + u);
+            }
         } else {
             // fewer sets (wide slot ranges: the accumulators leave room for two or three): nks need not divide, the last
             // one or two rounds reload conditionally
@@ -313,7 +425,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     if (EPI == 0 || EPI == 6 || EPI == 7) {
         // EPI 6 / 7: the shared term of a layer, stored WITH the layer's bias (6: on the value slot of the jets,
         // 7: on every walker column of the value chain), so the consuming GEMM starts its accumulators at S + b
-        T* Zp = Z + (size_t)w * z_walker_stride + (size_t)tile * Nout * P;
+        T* Zp = Z + (size_t)w * z_walker_stride + (EPI == 7 ? (size_t)tile * z_tile_stride : (size_t)tile * Nout * P);
 #pragma unroll
         for (int a = 0; a < NB; ++a)
 #pragma unroll
@@ -418,7 +530,8 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         // Z here is the next layer's G: [walker][tile][z_tile_stride / P rows][P]; the residual rows are rows n of the input tile
         const T* Gi = X + (size_t)w * x_walker_stride + (size_t)tile * x_tile_stride + lr;
         T* Go = Z + (size_t)w * z_walker_stride + (size_t)tile * z_tile_stride + lr;
-        layer_epilogue<T, NB, ST, EPI, NA>(acc, Gi, Go, stash, n0, lane, P);
+        if constexpr (SADD) layer_epilogue_sadd<T, NB, ST, NA, NSF>(acc, Gi, Go, stash, n0, lane, P, Sb + (size_t)w * Nout * P + lr, sfull, s0);
+        else layer_epilogue<T, NB, ST, EPI, NA>(acc, Gi, Go, stash, n0, lane, P);
     }
     stamp();
     if (EPI == 2 && oe.clk && wave == 0 && lane == 0) {

@@ -341,17 +341,20 @@ __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __re
 // spin s of h2[j][e] = (sum over the tiles that meet segment (e, s), in tile order) / n_s.   grid (N, groups), block 256.
 // Reads walk (feature, column-in-5) fastest -- contiguous in PARTM --, the result is transposed through LDS so that the
 // G rows are written column-contiguous.
+// grid.z: chunks of RC rows (RC divides K2: a chunk lies inside one partner spin) -- with few walker groups a workgroup per
+// (electron, group) was a 20-iteration chain of dependent loads on 168 CUs.
 template <typename T>
-__global__ void __launch_bounds__(256) k_m2_combine_val(SysDev<T> S, const T* __restrict__ PARTM, int K2, T* __restrict__ G, int row0) {
+__global__ void __launch_bounds__(256) k_m2_combine_val(SysDev<T> S, const T* __restrict__ PARTM, int K2, T* __restrict__ G, int row0, int RC) {
     constexpr int PV_ = 80;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* out = reinterpret_cast<T*>(smem_raw);                      // [nch*K2][PV]
+    T* out = reinterpret_cast<T*>(smem_raw);                      // [RC][PV]
     const int e = blockIdx.x, g = blockIdx.y, N = S.N, nt = S.NP / 16, nch = S.nch;
+    const int r0 = blockIdx.z * RC, sp = r0 / K2, k0 = r0 - sp * K2;
     const size_t blk = (size_t)PM_SLOTS * K2 * 5;
-    for (int idx = threadIdx.x; idx < nch * K2 * PV_; idx += blockDim.x) {
-        const int cc = idx % 5, k = (idx / 5) % K2, w5 = (idx / (5 * K2)) % (PV_ / 5), sp = idx / (PV_ * K2);
-        const int a = e * N + (sp == 0 ? 0 : S.n_up), ns = sp == 0 ? S.n_up : S.n_dn, b = a + ns;      // pairs [a, b)
-        const int seg = e * nch + sp;
+    const int a = e * N + (sp == 0 ? 0 : S.n_up), ns = sp == 0 ? S.n_up : S.n_dn, b = a + ns;      // pairs [a, b)
+    const int seg = e * nch + sp;
+    for (int idx = threadIdx.x; idx < RC * PV_; idx += blockDim.x) {
+        const int cc = idx % 5, kk = (idx / 5) % RC, w5 = idx / (5 * RC), k = k0 + kk;
         const T* pw = PARTM + ((size_t)g * (PV_ / 5) + w5) * nt * blk;
         T v = 0;
         for (int pt = a / 16; pt <= (b - 1) / 16; ++pt) {
@@ -359,11 +362,11 @@ __global__ void __launch_bounds__(256) k_m2_combine_val(SysDev<T> S, const T* __
             const int q = seg - seg0;                       // slots hold running sums over the tile's segments
             v += pw[(size_t)pt * blk + ((size_t)q * K2 + k) * 5 + cc] - (q > 0 ? pw[(size_t)pt * blk + ((size_t)(q - 1) * K2 + k) * 5 + cc] : T(0));
         }
-        out[(sp * K2 + k) * PV_ + w5 * 5 + cc] = v / T(ns);
+        out[kk * PV_ + w5 * 5 + cc] = v / T(ns);
     }
     __syncthreads();
-    T* Ge = G + ((size_t)(g * N + e) * S.ldk + row0) * PV_;
-    for (int idx = threadIdx.x; idx < nch * K2 * PV_; idx += blockDim.x) Ge[idx] = out[idx];
+    T* Ge = G + ((size_t)(g * N + e) * S.ldk + row0 + r0) * PV_;
+    for (int idx = threadIdx.x; idx < RC * PV_; idx += blockDim.x) Ge[idx] = out[idx];
 }
 
 // (3. one-electron stream layer and 4. orbital head: ds_gemm.h)

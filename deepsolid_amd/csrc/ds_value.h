@@ -182,11 +182,18 @@ __global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __r
 // largest |a[r][k]| among the rows not used yet, its owner broadcasts the row inside the quad, every other unused row is
 // reduced; det = sgn(order) * prod pivots, the sign from the number of unused rows skipped at each step.
 // Rows / columns n .. 4R-1 are padded with the identity.  Replaces jnp.linalg.slogdet at network.py:390 for the value chain.
-// grid (K, ceil(B / 64)), block 256 (4 waves x 16 walkers).
+// The determinant is carried as a complex product with its binary exponent apart (one rescale per pivot: no sqrt / log / division
+// per step); log|det| and the phase are taken once at the end.
+// grid (K, ceil(B / 64), channels), block 256 (4 waves x 16 walkers); channel sp0 + blockIdx.z uses offsets off.mout / off.dets [blockIdx.z].
+struct DetOff2 { size_t mout[2], dets[2]; };
+__device__ __forceinline__ int frexp_exp_(double x) { return __builtin_amdgcn_frexp_exp(x); }
+__device__ __forceinline__ int frexp_exp_(float x) { return __builtin_amdgcn_frexp_expf(x); }
 template <typename T, int R>
-__global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, size_t mout_off, int sp,
-                                                    long B, T* __restrict__ DETS, size_t dets_stride, size_t dets_off) {
+__global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, DetOff2 off, int sp0,
+                                                    long B, T* __restrict__ DETS, size_t dets_stride) {
     constexpr int NC = 4 * R;
+    const int sp = sp0 + blockIdx.z;
+    const size_t mout_off = off.mout[blockIdx.z], dets_off = off.dets[blockIdx.z];
     const int kdet = blockIdx.x, lane = threadIdx.x & 63, p = lane & 3;
     const long w = ((long)blockIdx.y * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
     const long wc = w < B ? w : B - 1;                   // the tail repeats the last walker (never stored)
@@ -203,8 +210,8 @@ __global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __rest
         }
     }
     unsigned used = 0;                                     // bit r: row r has been a pivot (the same in the four lanes)
-    T logabs = 0;
-    Cx<T> ph(1, 0);
+    Cx<T> ph(1, 0);                                        // det = ph * 2^pe
+    int pe = 0;
     const int qbase = lane & ~3;
 #pragma clang loop unroll(full)
     for (int k = 0; k < NC; ++k) {
@@ -237,9 +244,13 @@ __global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __rest
                 if (orr == rr) mine = a[rr][m];
             pv[m] = Cx<T>(__shfl(mine.re, owner), __shfl(mine.im, owner));
         }
-        const T ad = ds_sqrt(cx_abs2(pv[k]));
-        logabs += ds_log(ad);
-        ph = ph * Cx<T>(pv[k].re / ad, pv[k].im / ad);
+        ph = ph * pv[k];
+        {
+            const T am = fmax(ds_abs(ph.re), ds_abs(ph.im));
+            const int e = frexp_exp_(am);
+            ph = Cx<T>(ldexp(ph.re, -e), ldexp(ph.im, -e));
+            pe += e;
+        }
         const Cx<T> dinv = cx_inv(pv[k]);
 #pragma clang loop unroll(full)
         for (int rr = 0; rr < R; ++rr) {
@@ -254,7 +265,7 @@ __global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __rest
     }
     if (p == 0 && w < B) {
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
-        dw[0] = logabs;
+        dw[0] = T(0.5) * ds_log(cx_abs2(ph)) + T(pe) * T(0.69314718055994530942);
         dw[1] = ds_atan2(ph.im, ph.re);
     }
 }

@@ -27,4 +27,5 @@ e0.record()
 for r in range(3):
     xx, pm = step(params, xx, 2 + r, 0.02)
 e1.record(); torch.cuda.synchronize()
-print(f'{name} B={B} {dtype}: DS_VAL_WPB={os.environ.get("DS_VAL_WPB", "4")} forward {fwd:.3f} ms  mcmc_step {e0.elapsed_time(e1) / 3:.2f} ms  pmove {float(pm):.3f}  lp[0] {float(lp[0][0] if isinstance(lp, tuple) else lp[0]):.12f}')
+lp0 = lp[0] if isinstance(lp, tuple) else lp
+print(f'{name} B={B} {dtype}: DS_VAL_NB={os.environ.get("DS_VAL_NB", "auto")} sum(lp) {float(lp0.double().sum()).hex()} forward {fwd:.3f} ms  mcmc_step {e0.elapsed_time(e1) / 3:.2f} ms  pmove {float(pm):.3f}  lp[0] {float(lp[0][0] if isinstance(lp, tuple) else lp[0]):.12f}')
