@@ -186,8 +186,10 @@ __global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __r
 // per step); log|det| and the phase are taken once at the end.
 // grid (K, ceil(B / 64), channels), block 256 (4 waves x 16 walkers); channel sp0 + blockIdx.z uses offsets off.mout / off.dets [blockIdx.z].
 struct DetOff2 { size_t mout[2], dets[2]; };
-__device__ __forceinline__ int frexp_exp_(double x) { return __builtin_amdgcn_frexp_exp(x); }
-__device__ __forceinline__ int frexp_exp_(float x) { return __builtin_amdgcn_frexp_expf(x); }
+__device__ __forceinline__ int ds_frexp_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }
+__device__ __forceinline__ int ds_frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
+__device__ __forceinline__ float ds_ldexp(float x, int e) { return ldexpf(x, e); }
+__device__ __forceinline__ double ds_ldexp(double x, int e) { return ldexp(x, e); }
 template <typename T, int R>
 __global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __restrict__ MOUT, size_t mout_stride, DetOff2 off, int sp0,
                                                     long B, T* __restrict__ DETS, size_t dets_stride) {
@@ -246,9 +248,9 @@ __global__ void __launch_bounds__(256) k_det_lu_val(SysDev<T> S, const T* __rest
         }
         ph = ph * pv[k];
         {
-            const T am = fmax(ds_abs(ph.re), ds_abs(ph.im));
-            const int e = frexp_exp_(am);
-            ph = Cx<T>(ldexp(ph.re, -e), ldexp(ph.im, -e));
+            const T big = ds_abs(ph.re) > ds_abs(ph.im) ? ds_abs(ph.re) : ds_abs(ph.im);      // (NaN: the exponent is ignored, NaN stays)
+            const int e = big > T(0) ? ds_frexp_exp(big) : 0;
+            ph = Cx<T>(ds_ldexp(ph.re, -e), ds_ldexp(ph.im, -e));
             pe += e;
         }
         const Cx<T> dinv = cx_inv(pv[k]);
@@ -296,10 +298,6 @@ template <typename T, int NC> struct LuState {
     int esum;
     Cx<T> ph;
 };
-__device__ __forceinline__ int ds_frexp_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }
-__device__ __forceinline__ int ds_frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
-__device__ __forceinline__ float ds_ldexp(float x, int e) { return ldexpf(x, e); }
-__device__ __forceinline__ double ds_ldexp(double x, int e) { return ldexp(x, e); }
 template <typename T, int NC, int K>
 __device__ __forceinline__ void lu_wave_step(Cx<T> (&a)[NC], LuState<T, NC>& st, int n, int lane) {
     if (K >= n) return;

@@ -483,6 +483,51 @@ def test_value_chain_log_det_propagates_nan():
     assert torch.equal(x1[2], x0[2]) and abs(float(pm) - 0.75) < 1e-12
 
 
+def test_value_chain_wave_tiles_are_bit_identical(monkeypatch):
+    """The value chain picks the wave tile of its GEMMs from the number of workgroups a launch would have (16- / 32- / 64-feature
+    waves; the shared term in 16-walker column blocks next to the narrow ones): the same products in the same order, so log|psi|
+    and the phase must be BIT-identical whatever DS_VAL_NB (read at system creation) forces -- small test batches take the
+    16-feature kernels by default, the 4096-walker benchmark the 64-feature ones."""
+    from deepsolid_amd import systems
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case('bcc_li')
+    dp = dev_params(params)
+    x = torch.as_tensor(np.concatenate([fx['x'][:3], systems.synthetic_walkers(cell, 160, seed=4)]), device='cuda')
+    out = {}
+    for nb in ('', '1', '2', '4'):
+        monkeypatch.delenv('DS_VAL_NB', raising=False)
+        if nb:
+            monkeypatch.setenv('DS_VAL_NB', nb)
+        la, ph = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).logpsi(dp, x)
+        out[nb] = (la.clone(), ph.clone())
+    for nb in ('1', '2', '4'):
+        assert torch.equal(out[nb][0], out[''][0]) and torch.equal(out[nb][1], out[''][1]), nb
+    np.testing.assert_allclose(out['4'][0][:3].cpu().numpy(), fx['logabs'][:3], atol=1e-9)
+
+
+@pytest.mark.parametrize('nelec', [(12, 10), (10, 6)])
+def test_value_chain_log_det_channels_of_different_sizes(nelec):
+    """k_det_lu_val factorises both spin channels' matrices in one launch when they take the same register instance (12 x 12 and
+    10 x 10: rows / columns padded with the identity), in two launches otherwise (10 x 10 and 6 x 6); the determinant is carried
+    as a scaled complex product.  log|psi| and phase of charged bcc-Li cells against the oracle."""
+    from deepsolid_amd import network, systems
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('bcc_li', nelec=nelec)
+    net_kw = dict(systems.DETNET_DEFAULTS)
+    params = make_test_params(78, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    xn = systems.synthetic_walkers(cell, 3, seed=9)
+    ps = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_phase_and_slogdet', **net_kw)
+    phase, logabs = ps.apply(dp, torch.as_tensor(xn, device='cuda'))
+    o_ps = oracle_net(cell, klist, net_kw, 'eval_phase_and_slogdet')
+    for b in range(3):
+        ph_ref, la_ref = o_ps.apply(p_cpu, tt(xn[b]))
+        assert abs(float(logabs[b]) - float(la_ref)) < 1e-10
+        assert abs(complex(phase[b].cpu()) - complex(ph_ref)) < 1e-10
+
+
 def test_row_split_trace_kernel_float64():
     """32 x 32 matrices in float64: the only size at which the row-split trace kernel (k_det_trace_mfma_split, the kernel of the
     float32 diamond benchmark) runs in double precision -- no fixture has it.  One walker of a charged, spin-polarised bcc-Li 2x2x2
