@@ -118,36 +118,41 @@ __global__ void __launch_bounds__(256) k_features_val(SysDev<T> S, const T* __re
         Mw[idx] = v / T(ns);
     }
     T* Qw = Q + (size_t)g * N * S.nparam_max * 2 * PV;
-    for (int idx = tid; idx < N * S.nparam_max * PV; idx += nt) {
-        const int c = idx % PV, p = (idx / PV) % S.nparam_max, i = idx / (PV * S.nparam_max);
-        const int s = spin_of(i, S.n_up), np = S.nparam[s];
-        if (p >= np) continue;
+    // q[i][p] = envelope(i, p) * exp(i k_m . x_i), p = (determinant, orbital m): the Bloch phase belongs to the orbital's k-point, one
+    // sincos per (electron, m, walker) serves all determinants
+    const int norb_max = S.norb[0] > S.norb[S.nch - 1] ? S.norb[0] : S.norb[S.nch - 1];
+    for (int idx = tid; idx < N * norb_max * PV; idx += nt) {
+        const int c = idx % PV, m = (idx / PV) % norb_max, i = idx / (PV * norb_max);
+        const int s = spin_of(i, S.n_up), np = S.nparam[s], no = S.norb[s];
+        if (m >= no) continue;
         const T* pi_ = s == 0 ? env_pi0 : env_pi1;
         const T* sg_ = s == 0 ? env_sg0 : env_sg1;
-        T e = 0;
-        for (int a = 0; a < A; ++a) {
-            const T* f = Gw + ((size_t)i * S.ldk + nf * a) * PV + c;    // rows sd, rel_x, rel_y, rel_z (, cos-rel) of atom a
-            T r;
-            if (S.env_type == 0) r = ds_abs(f[0] * sg_[a * np + p]);
-            else {
-                T r2 = 0;
-                for (int m = 0; m < 3; ++m) {
-                    T u = 0;
-                    if (S.env_type == 1) u = sg_[(a * 3 + m) * np + p] * f[(size_t)(1 + m) * PV];
-                    else
-                        for (int k = 0; k < 3; ++k) u += sg_[((k * 3 + m) * A + a) * np + p] * f[(size_t)(1 + k) * PV];
-                    r2 += u * u;
-                }
-                r = ds_sqrt(r2);
-            }
-            e += pi_[a * np + p] * ds_exp(-r);
-        }
-        const T* kv = S.klist[s] + 3 * (p % S.norb[s]);
+        const T* kv = S.klist[s] + 3 * m;
         const T* xp = x + (size_t)walker(c) * 3 * N + 3 * i;
         T sn, cs;
         ds_sincos(kv[0] * xp[0] + kv[1] * xp[1] + kv[2] * xp[2], &sn, &cs);
-        Qw[((size_t)(i * S.nparam_max + p) * 2) * PV + c] = e * cs;
-        Qw[((size_t)(i * S.nparam_max + p) * 2 + 1) * PV + c] = e * sn;
+        for (int p = m; p < np; p += no) {
+            T e = 0;
+            for (int a = 0; a < A; ++a) {
+                const T* f = Gw + ((size_t)i * S.ldk + nf * a) * PV + c;    // rows sd, rel_x, rel_y, rel_z (, cos-rel) of atom a
+                T r;
+                if (S.env_type == 0) r = ds_abs(f[0] * sg_[a * np + p]);
+                else {
+                    T r2 = 0;
+                    for (int mm = 0; mm < 3; ++mm) {
+                        T u = 0;
+                        if (S.env_type == 1) u = sg_[(a * 3 + mm) * np + p] * f[(size_t)(1 + mm) * PV];
+                        else
+                            for (int k = 0; k < 3; ++k) u += sg_[((k * 3 + mm) * A + a) * np + p] * f[(size_t)(1 + k) * PV];
+                        r2 += u * u;
+                    }
+                    r = ds_sqrt(r2);
+                }
+                e += pi_[a * np + p] * ds_exp(-r);
+            }
+            Qw[((size_t)(i * S.nparam_max + p) * 2) * PV + c] = e * cs;
+            Qw[((size_t)(i * S.nparam_max + p) * 2 + 1) * PV + c] = e * sn;
+        }
     }
 }
 
