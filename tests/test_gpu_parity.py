@@ -483,7 +483,8 @@ def test_value_chain_log_det_propagates_nan():
     assert torch.equal(x1[2], x0[2]) and abs(float(pm) - 0.75) < 1e-12
 
 
-def test_value_chain_wave_tiles_are_bit_identical(monkeypatch):
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_value_chain_wave_tiles_are_bit_identical(dtype, monkeypatch):
     """The value chain picks the wave tile of its GEMMs from the number of workgroups a launch would have (16- / 32- / 64-feature
     waves; the shared term in 16-walker column blocks next to the narrow ones): the same products in the same order, so log|psi|
     and the phase must be BIT-identical whatever DS_VAL_NB (read at system creation) forces -- small test batches take the
@@ -492,18 +493,18 @@ def test_value_chain_wave_tiles_are_bit_identical(monkeypatch):
     from deepsolid_amd.device import DeviceSystem
     from deepsolid_amd.ewaldsum import EwaldTables
     fx, cell, klist, net_kw, params = load_case('bcc_li')
-    dp = dev_params(params)
-    x = torch.as_tensor(np.concatenate([fx['x'][:3], systems.synthetic_walkers(cell, 160, seed=4)]), device='cuda')
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=dtype, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    x = torch.as_tensor(np.concatenate([fx['x'][:3], systems.synthetic_walkers(cell, 160, seed=4)]), dtype=dtype, device='cuda')
     out = {}
     for nb in ('', '1', '2', '4'):
         monkeypatch.delenv('DS_VAL_NB', raising=False)
         if nb:
             monkeypatch.setenv('DS_VAL_NB', nb)
-        la, ph = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).logpsi(dp, x)
+        la, ph = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), dtype).logpsi(dp, x)
         out[nb] = (la.clone(), ph.clone())
     for nb in ('1', '2', '4'):
         assert torch.equal(out[nb][0], out[''][0]) and torch.equal(out[nb][1], out[''][1]), nb
-    np.testing.assert_allclose(out['4'][0][:3].cpu().numpy(), fx['logabs'][:3], atol=1e-9)
+    np.testing.assert_allclose(out['4'][0][:3].double().cpu().numpy(), fx['logabs'][:3], atol=1e-9 if dtype == torch.float64 else 2e-3)
 
 
 @pytest.mark.parametrize('nelec', [(12, 10), (10, 6)])
