@@ -759,7 +759,8 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         if (Kh == Nout && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         dim3 block; unsigned gz;
         gemm_geom(Nout, 4, &block, &gz);
-        const int nbh = val_nb(s->val_nb, (int64_t)S.N * ng * gz);
+        // (a float32 MFMA lasts half as long: the same rule on half the count -- diamond, 1024 walkers: forward 3.46 -> 3.40 ms)
+        const int nbh = val_nb(s->val_nb, (int64_t)S.N * ng * gz / (sizeof(T) == 4 ? 2 : 1));
         if (l == 0)
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 7>), dim3(1, (unsigned)ng, gz), block, 0, st, (const T*)nullptr, (size_t)0, (size_t)0,
                                (const T*)nullptr, 0, vb.MEAN0, (size_t)Ksh * PV, blk(s->i_wsh[l]), Ksh, 0, ZB, (size_t)Nout * PV, (size_t)0, Nout, PV,
@@ -827,7 +828,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         // 192 columns would be three 64-column waves per workgroup: 48-column waves give four balanced ones (as in the
         // forward-Laplacian chain's orbital head): 131 -> 94 us per 4096 bcc-Li walkers
         const bool w48 = OC % 256 != 0 && OC % 192 == 0;
-        const int nbo = val_nb(s->val_nb, (int64_t)ns * ng * (w48 ? OC / 192 : ogz));
+        const int nbo = val_nb(s->val_nb, (int64_t)ns * ng * (w48 ? OC / 192 : ogz) / (sizeof(T) == 4 ? 2 : 1));
         if (nbo < 4) DS_VORB(1, dim3(256), (unsigned)((OC + 63) / 64));
         else if (w48) DS_VORB(3, dim3(256), (unsigned)(OC / 192));
         else DS_VORB(4, oblock, ogz);
