@@ -34,6 +34,47 @@ def _require_gpu():
                            'oracle/ and is test infrastructure only)')
 
 
+def device_widths(hidden_dims, n_in_ref, n_double=None):
+    """The widths the kernels run for the reference's `hidden_dims` (network.py:111-132).
+
+    The kernels need one-electron widths in multiples of 64 and pair widths of 16 or 32; any other width is run with ZERO-PADDED
+    weights and biases, which is exact: a padded feature is tanh(0) = 0 in every layer, has zero jets, adds nothing to the spin
+    means and meets zero rows in the next layer.  The residual connections follow the reference's widths (network.py:525-528:
+    in == out), and the library decides them from the widths it is given, so the padded widths of consecutive layers are made
+    equal exactly where the reference's are (one more block of padding where two different widths would pad to the same one).
+    `n_in_ref`: width of the one-electron input features (the library pads it to the MFMA k-step, a multiple of 4);
+    `n_double`: number of pair layers that run (network.py:118-121: the last width is unused without `use_last_layer`)."""
+    n_double = len(hidden_dims) if n_double is None else n_double
+    h1, h2 = [], []
+    n_in_single = (int(n_in_ref) + 3) // 4 * 4
+    for l, (a, b) in enumerate(hidden_dims):
+        a, b = int(a), int(b)
+        if a < 1 or b < 1:
+            raise ValueError(f'hidden_dims[{l}] = {(a, b)}')
+        if b > 32:
+            raise ValueError(f'hidden_dims[{l}][1] = {b}: pair-stream widths beyond 32 have no kernel instance')
+        pa, pb = (a + 63) // 64 * 64, (16 if b <= 16 else 32)
+        if l == 0:
+            if pa == n_in_single and a != int(n_in_ref):
+                pa += 64
+        else:
+            ra, rb = int(hidden_dims[l - 1][0]), int(hidden_dims[l - 1][1])
+            if a == ra:
+                pa = h1[-1]
+            elif pa == h1[-1]:
+                pa += 64
+            if b == rb:
+                pb = h2[-1]
+            elif pb == h2[-1] and l < n_double:
+                if pb == 32:
+                    raise ValueError(f'hidden_dims[{l - 1}][1] = {rb} and hidden_dims[{l}][1] = {b} differ and both need the 32-wide '
+                                     'pair kernels: no padded width keeps them apart')
+                pb = 32
+        h1.append(pa)
+        h2.append(pb)
+    return tuple(zip(h1, h2))
+
+
 class DeviceSystem:
     def __init__(self, simulation_cell, klist, net_kw, tables, dtype=torch.float64, device=None):
         _require_gpu()
@@ -48,6 +89,9 @@ class DeviceSystem:
         self.n = sum(self.nelec)
         self.n_det = int(net_kw['determinants'])
         self.hidden_dims = tuple(tuple(int(v) for v in h) for h in net_kw['hidden_dims'])
+        nf_in = (4 if net_kw.get('distance_type', 'nu') == 'nu' else 7) * np.asarray(prim.atom_coords()).reshape(-1, 3).shape[0]
+        self.device_dims = device_widths(self.hidden_dims, nf_in,      # what the kernels run (zero-padded weights)
+                                         len(self.hidden_dims) - (0 if net_kw.get('use_last_layer', False) else 1))
         d = _lib.SystemDesc()
         keep = []                       # host arrays must outlive ds_system_create
 
@@ -70,7 +114,7 @@ class DeviceSystem:
             flat[:3 * n_sym] = np.asarray(src, dtype=np.float64).reshape(-1)
             getattr(d, name)[:] = flat.tolist()
         d.n_layers = len(self.hidden_dims)
-        for i, (a, b) in enumerate(self.hidden_dims):
+        for i, (a, b) in enumerate(self.device_dims):
             d.hidden_single[i], d.hidden_double[i] = a, b
         d.n_det = self.n_det
         d.distance_type = {'nu': 0, 'tri': 1}.get(net_kw.get('distance_type', 'nu'), 99)
@@ -206,29 +250,36 @@ class DeviceSystem:
         natom = np.asarray(self.cell.original_cell.atom_coords()).reshape(-1, 3).shape[0]
         nf = 4 if self.net_kw.get('distance_type', 'nu') == 'nu' else 7
         r4 = lambda v: (v + 3) // 4 * 4
-        # reference widths (network.py:111-132) and the device widths (layer-0 rows padded to the MFMA k-step)
+        # reference widths (network.py:111-132) and the device widths (layer-0 rows padded to the MFMA k-step, hidden widths
+        # to what the kernels run: device_widths)
         h1_ref = [nf * natom] + [h[0] for h in self.hidden_dims]
         h2_ref = [nf] + [h[1] for h in self.hidden_dims]
-        h1 = [r4(nf * natom)] + h1_ref[1:]
-        h2 = [r4(nf)] + h2_ref[1:]
+        h1 = [r4(nf * natom)] + [h[0] for h in self.device_dims]
+        h2 = [r4(nf)] + [h[1] for h in self.device_dims]
 
         def pad_rows(m, rows):
             if m.shape[0] == rows:
                 return m
             return torch.cat([m, torch.zeros(rows - m.shape[0], m.shape[1], dtype=m.dtype, device=m.device)], dim=0)
+
+        def pad_cols(m, cols):
+            if m.shape[-1] == cols:
+                return m
+            return torch.cat([m, torch.zeros(*m.shape[:-1], cols - m.shape[-1], dtype=m.dtype, device=m.device)], dim=-1)
         for l in range(len(self.hidden_dims)):
             w = dev(params['single'][l]['w'])
             kh, k2, khp, k2p = h1_ref[l], h2_ref[l], h1[l], h2[l]
-            if w.shape[0] != (nch + 1) * kh + nch * k2:
-                raise ValueError(f"single[{l}]['w'] has {w.shape[0]} rows, expected {(nch + 1) * kh + nch * k2}")
+            if w.shape[0] != (nch + 1) * kh + nch * k2 or w.shape[1] != h1_ref[l + 1]:
+                raise ValueError(f"single[{l}]['w'] has shape {tuple(w.shape)}, expected {((nch + 1) * kh + nch * k2, h1_ref[l + 1])}")
+            w = pad_cols(w, h1[l + 1])
             m2 = [pad_rows(w[(nch + 1) * kh + c * k2:(nch + 1) * kh + (c + 1) * k2], k2p) for c in range(nch)]
             put(torch.cat([pad_rows(w[:kh], khp)] + m2, dim=0))                       # per-electron rows [h | m2_up | m2_dn]
             put(torch.cat([pad_rows(w[(1 + c) * kh:(2 + c) * kh], khp) for c in range(nch)], dim=0))   # spin-mean rows
-            put(dev(params['single'][l]['b']))
+            put(pad_cols(dev(params['single'][l]['b']).reshape(1, -1), h1[l + 1]))
         use_last = bool(self.net_kw.get('use_last_layer', False))
         for l in range(len(self.hidden_dims) - (0 if use_last else 1)):
-            put(pad_rows(dev(params['double'][l]['w']), h2[l]))
-            put(dev(params['double'][l]['b']))
+            put(pad_cols(pad_rows(dev(params['double'][l]['w']), h2[l]), h2[l + 1]))
+            put(pad_cols(dev(params['double'][l]['b']).reshape(1, -1), h2[l + 1]))
         full_det = bool(self.net_kw.get('full_det', False))
         for c in range(nch):
             norb = self.n if full_det else self.nelec[c]
@@ -246,12 +297,13 @@ class DeviceSystem:
                 packed[:, torch.as_tensor(np.nonzero(valid)[0], device=self.device)] = \
                     mat[:, torch.as_tensor(src[valid], device=self.device)]
                 flat[off:off + rows * cols] = packed.reshape(-1)
-            kh, k2 = h1[-1], h2[-1]
+            kh, k2, khp, k2p = h1_ref[-1], h2_ref[-1], h1[-1], h2[-1]
             if use_last:      # rows [h | mean_up | mean_dn | m2_up | m2_dn] (network.py:126-128) -> per-electron / shared
-                put_packed(torch.cat([w[:kh], w[(nch + 1) * kh:]], dim=0))
-                put_packed(w[kh:(nch + 1) * kh])
+                m2 = [pad_rows(w[(nch + 1) * kh + cc * k2:(nch + 1) * kh + (cc + 1) * k2], k2p) for cc in range(nch)]
+                put_packed(torch.cat([pad_rows(w[:kh], khp)] + m2, dim=0))
+                put_packed(torch.cat([pad_rows(w[(1 + cc) * kh:(2 + cc) * kh], khp) for cc in range(nch)], dim=0))
             else:
-                put_packed(w)
+                put_packed(pad_rows(w, khp))
             if self.net_kw.get('bias_orbitals', False):
                 put(dev(params['orbital'][c]['b']))
             put(dev(params['envelope'][c]['pi']))

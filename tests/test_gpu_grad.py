@@ -167,6 +167,35 @@ def test_energy_gradient_vs_oracle(clip_type, clip):
     assert_tree_close(grads, g_ref, 1e-7)
 
 
+@pytest.mark.parametrize('hidden_dims,use_last', [(((40, 10), (56, 12), (56, 12)), False), (((100, 20), (100, 20)), True)])
+def test_hidden_widths_without_kernel_instances(hidden_dims, use_last):
+    """Widths the kernels have no instance for (one-electron widths that are not multiples of 64, pair widths other than 16 / 32)
+    run with zero-padded weights (deepsolid_amd/device.py::device_widths): exact, because a padded feature is tanh(0) = 0 in every
+    layer.  The residual connections must follow the REFERENCE widths (network.py:525-528): 40 -> 56 has none although both pad
+    to 64 (the second becomes 128), 56 -> 56 has one; 10 -> 12 has none (16 and 32), 12 -> 12 has one.  Loss, local energies and
+    the energy gradient -- mapped back to the reference's parameter shapes -- against the oracle; the same tree must be refused
+    where no padding can keep two different pair widths apart."""
+    from deepsolid_amd import network as dnet, train as dtrain
+    from deepsolid_amd.device import device_widths
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('lih')
+    net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=hidden_dims, use_last_layer=use_last)
+    params = make_test_params(17, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    net = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    loss_fn = dtrain.make_loss(net.apply, None, cell, clip_local_energy=5.0, clip_type='real')
+    dp = dev_params(params)
+    xn = systems.synthetic_walkers(cell, 5, seed=21)
+    (loss, aux), grads = loss_fn.value_and_grad(dp, torch.as_tensor(xn, device='cuda'))
+    onet_ = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    oloss = otrain.make_loss(onet_.apply, cell, mode='hessian', clip_local_energy=5.0, clip_type='real')
+    (l_ref, aux_ref), g_ref = oloss.value_and_grad(params, torch.as_tensor(xn))
+    assert abs(float(loss) - float(l_ref)) < 1e-8
+    assert float((aux.local_energy.cpu() - aux_ref.local_energy).abs().max()) < 1e-8
+    assert_tree_close(grads, g_ref, 1e-7)
+    with pytest.raises(ValueError):
+        device_widths(((64, 20), (64, 24), (64, 24)), 4)
+
+
 def test_training_step_runs_and_lowers_the_energy_estimate():
     """train.make_training_step (train.py:147-184) with Adam: a few steps on LiH from a fixed seed."""
     from deepsolid_amd import network as dnet, qmc, train as dtrain

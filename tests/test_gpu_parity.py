@@ -358,6 +358,31 @@ def test_lowrank_layer_other_architectures_vs_oracle(hidden_dims, nelec, monkeyp
     assert np.abs(out[None] - out['1']).max() < 1e-10 * max(1.0, np.abs(out['1']).max())
 
 
+def test_padded_hidden_widths_on_the_benchmark_cell_vs_oracle():
+    """hidden_dims ((100, 20),) * 3 on the 24-electron cell: the kernels run 128 / 32 with zero-padded weights (the low-rank first
+    hidden layer included): log|psi|, phase and E_kin against the oracle, which runs the reference's widths."""
+    from deepsolid_amd import hamiltonian, network, systems
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('bcc_li')
+    net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=((100, 20),) * 3)
+    params = make_test_params(19, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    xn = systems.synthetic_walkers(cell, 2, seed=10)
+    x = torch.as_tensor(xn, device='cuda')
+    ps = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_phase_and_slogdet', **net_kw)
+    phase, logabs = ps.apply(dp, x)
+    ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    ke, _ = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, x)
+    o_ps = oracle_net(cell, klist, net_kw, 'eval_phase_and_slogdet')
+    for b in range(2):
+        st = ofl.stages(p_cpu, tt(xn[b]), klist, cell, net_kw)
+        ph_ref, la_ref = o_ps.apply(p_cpu, tt(xn[b]))
+        assert abs(float(logabs[b]) - float(la_ref)) < 1e-10
+        assert abs(complex(phase[b].cpu()) - complex(ph_ref)) < 1e-10
+        assert abs(complex(ke[b].cpu()) - complex(st['ke'])) < 1e-9 * max(1.0, abs(complex(st['ke'])))
+
+
 @pytest.mark.parametrize('name', ['bcc_li_333', 'graphene_hex'])
 def test_blocked_determinant_traces_vs_scalar_kernel(name, monkeypatch):
     """Matrix sizes without a compile-time trace instance (odd sizes, float64 matrices whose slot tile of Y exceeds the LDS) run
