@@ -1356,7 +1356,7 @@ int check_arch(const ds_system_desc* d) {
     if (d->n_up < 1) return fail("n_up must be >= 1");
     if (d->n_dn < 0) return fail("n_dn must be >= 0");
     if (d->n_layers < 1 || d->n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
-    if (d->n_det < 1 || d->n_det > 32) return fail("n_det must be in 1..32");
+    if (d->n_det < 1 || d->n_det > DS_MAX_DETS) return fail("n_det must be in 1..%d", DS_MAX_DETS);
     if (d->n_sym < 3 || d->n_sym > DS_MAX_SYM) return fail("bad n_sym");
     // every shape limit of the kernels is checked HERE, so that a handle that was created never fails at its first launch
     const int N = d->n_up + d->n_dn, tiles = (3 * N + 2 + 15) / 16, nmat = d->full_det ? N : std::max(d->n_up, d->n_dn);

@@ -21,6 +21,9 @@
 #define DS_EXP(x) (false)
 #endif
 
+// determinants per wave function (the log-sum-exp kernels keep one log|det| / phase / weight per determinant in private arrays)
+#define DS_MAX_DETS 64
+
 namespace ds {
 
 template <typename T> struct Acc4;

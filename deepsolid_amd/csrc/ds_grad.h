@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(64) k_det_weights(SysDev<T> S, const T* __rest
         return;
     }
     const T* Dw = DETS + (size_t)w * dets_stride;
-    T la[32], ar[32];
+    T la[DS_MAX_DETS], ar[DS_MAX_DETS];
     T mx = -1e300;
     for (int k = 0; k < K; ++k) {
         la[k] = Dw[4 * k]; ar[k] = Dw[4 * k + 1];

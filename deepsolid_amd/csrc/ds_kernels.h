@@ -1101,7 +1101,7 @@ __global__ void __launch_bounds__(64) k_combine(SysDev<T> S, const T* __restrict
     const T* Tw = TR + (size_t)w * tr_stride;
     const T* Dw = DETS + (size_t)w * dets_stride;
     // log D_k
-    T la[32], ar[32];
+    T la[DS_MAX_DETS], ar[DS_MAX_DETS];
     T mx = -1e300;
     for (int k = 0; k < K; ++k) {
         la[k] = Dw[4 * k]; ar[k] = Dw[4 * k + 1];
@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(64) k_combine(SysDev<T> S, const T* __restrict
         mx = la[k] > mx ? la[k] : mx;
     }
     Cx<T> sum(0, 0);
-    Cx<T> wk[32];
+    Cx<T> wk[DS_MAX_DETS];
     for (int k = 0; k < K; ++k) {
         T sn, cs;
         ds_sincos(ar[k], &sn, &cs);

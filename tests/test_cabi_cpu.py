@@ -116,7 +116,7 @@ def test_shape_limits_are_rejected_at_create():
     """Every shape the kernels cannot run is refused by ds_system_create itself (check_arch runs before any device
     allocation, so this needs no GPU): a handle that was created never fails at its first launch.  The supported set is
     documented in DESIGN.md section 1: determinant matrices up to 64 x 64 (hence N <= 128 electrons, or 64 with full_det:
-    jet-slot tiles 1..25 all have kernel instances), hidden_single multiples of 64 up to 1024, hidden_double 16 or 32, up to 32
+    jet-slot tiles 1..25 all have kernel instances), hidden_single multiples of 64 up to 1024, hidden_double 16 or 32, up to 64
     determinants."""
     import ctypes as C
     from deepsolid_amd import _lib
@@ -150,7 +150,7 @@ def test_shape_limits_are_rejected_at_create():
     assert 'hidden_single' in err(hidden_single=[256, 200, 256])
     assert 'hidden_single' in err(hidden_single=[2048, 256, 256])
     assert 'hidden_double' in err(hidden_double=[32, 24, 32])
-    assert 'n_det' in err(n_det=33)
+    assert 'n_det' in err(n_det=65)
     assert 'n_up' in err(n_up=0)
     assert 'n_dn' in err(n_dn=-1)
     assert 'tri' in err(distance_type=1, envelope_type=2)

@@ -196,6 +196,25 @@ def test_hidden_widths_without_kernel_instances(hidden_dims, use_last):
         device_widths(((64, 20), (64, 24), (64, 24)), 4)
 
 
+def test_forty_determinants():
+    """More than 32 determinants (the reference has no bound; the library's is 64 since round 4): loss, local energies and energy
+    gradient of a 40-determinant LiH wave function against the oracle."""
+    from deepsolid_amd import network as dnet, train as dtrain
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('lih')
+    net_kw = dict(systems.DETNET_DEFAULTS, determinants=40)
+    params = make_test_params(23, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    net = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    loss_fn = dtrain.make_loss(net.apply, None, cell, clip_local_energy=5.0, clip_type='real')
+    xn = systems.synthetic_walkers(cell, 4, seed=22)
+    (loss, aux), grads = loss_fn.value_and_grad(dev_params(params), torch.as_tensor(xn, device='cuda'))
+    oloss = otrain.make_loss(oracle_net(cell, klist, net_kw, 'eval_logdet').apply, cell, mode='hessian', clip_local_energy=5.0, clip_type='real')
+    (l_ref, aux_ref), g_ref = oloss.value_and_grad(params, torch.as_tensor(xn))
+    assert abs(float(loss) - float(l_ref)) < 1e-8
+    assert float((aux.local_energy.cpu() - aux_ref.local_energy).abs().max()) < 1e-8
+    assert_tree_close(grads, g_ref, 1e-7)
+
+
 def test_training_step_runs_and_lowers_the_energy_estimate():
     """train.make_training_step (train.py:147-184) with Adam: a few steps on LiH from a fixed seed."""
     from deepsolid_amd import network as dnet, qmc, train as dtrain
