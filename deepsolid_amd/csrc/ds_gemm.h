@@ -12,6 +12,8 @@
 
 #include "ds_kernels.h"
 
+// The dense 24-electron hidden-layer instance adds the shared term S in its epilogue (layer_epilogue_sadd); compile-time switches
+// of that variant, kept for A/B builds (-DDS_SADD=0: accumulators start at S as in every other instance)
 #ifndef DS_SADD
 #define DS_SADD 1
 #endif
@@ -379,8 +381,9 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 for (int u = 0; u < 4; ++u) { step(u, ks + u); load_set(u); }
             }
             if constexpr (SADD) {
-                // the last four k-steps reload nothing: the rows of S go into the registers of the sets as they die
-                // (5 full row groups = 25 values + the value-tile entries of the other 11 groups = 36 = the ring)
+                // the last four k-steps reload nothing: rows of S go into the registers of the sets as they die -- the full rows of
+                // the first NSF row groups and the value-tile entries of all sixteen (NSF = 2: 10 + 14 values; 5 would fill the
+                // 36 registers of the ring but spills 68 bytes and measured slower)
                 const T* Sp0 = Sb + (size_t)w * Nout * P + lr;
                 auto srow = [&](int q) { return Sp0 + (size_t)(n0 + 16 * (q >> 2) + acc_row<T>(lane, q & 3)) * P; };
                 auto lfull = [&](int q) {
