@@ -669,7 +669,9 @@ def test_float32_error_budget(name):
     oracle's autodiff `hessian` mode and its forward-Laplacian mode run in float32 on the CPU) next to what the HIP float32
     chain loses, both against the float64 value at the float32-rounded walker, on every reference-executed walker (4 for
     diamond).  Per walker the HIP chain must not be worse than 3x the float32 restatement at that walker (or 3x the case's
-    mean loss where the restatement happens to land close; +1e-6 relative floor); the numbers are printed for the record."""
+    mean loss where the restatement happens to land close; +1e-6 relative floor); the numbers are printed for the record.
+    The autodiff restatement runs up to 24 electrons: at 96 it takes 27 s of the GPU suite for a number the bound does not
+    need (measured once: 5.6e-5 on diamond walker 0, where the HIP chain loses 9.6e-6 and the bound is 4.6e-4)."""
     from deepsolid_amd import hamiltonian, network
     fx, cell, klist, net_kw, params = load_case(name)
     nb = len(fx['ke_ref']) if name == 'diamond' else 2
@@ -681,11 +683,13 @@ def test_float32_error_budget(name):
     p32 = onet.params_to_torch(params, dtype=torch.float32)
     ref, e_fl = float32_budget(name, nb)
     e_hip = [abs(complex(ke[b].cpu()) - ref[b]) / max(1.0, abs(ref[b])) for b in range(nb)]
-    with onet.working_dtype(torch.float32):               # the autodiff restatement on walker 0 only (CPU cost)
-        net32 = oracle_net(cell, klist, net_kw, 'eval_logdet')
-        e_ad = abs(complex(sum(oham.local_kinetic_energy_real_imag_hessian(net32.apply)(p32, x32[0]))) - ref[0]) / max(1.0, abs(ref[0]))
+    e_ad = 0.0
+    if sum(cell.nelec) <= 24:
+        with onet.working_dtype(torch.float32):           # the autodiff restatement on walker 0 only (CPU cost)
+            net32 = oracle_net(cell, klist, net_kw, 'eval_logdet')
+            e_ad = abs(complex(sum(oham.local_kinetic_energy_real_imag_hessian(net32.apply)(p32, x32[0]))) - ref[0]) / max(1.0, abs(ref[0]))
     print(f'{name}: relative E_kin error in float32 per walker -- HIP ' + ' '.join(f'{e:.2e}' for e in e_hip) +
-          ' | forward-Laplacian restatement ' + ' '.join(f'{e:.2e}' for e in e_fl) + f' | autodiff restatement (walker 0) {e_ad:.2e}')
+          ' | forward-Laplacian restatement ' + ' '.join(f'{e:.2e}' for e in e_fl) + ' | autodiff restatement (walker 0) ' + (f'{e_ad:.2e}' if e_ad else 'not run'))
     for b in range(nb):
         bound = max(float32_tolerance(e_fl, b), 3 * e_ad + 1e-6 if b == 0 else 0.0)
         assert e_hip[b] <= bound, (b, e_hip, e_fl, e_ad)
