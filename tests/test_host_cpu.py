@@ -369,3 +369,32 @@ def test_klist_from_a_saved_hf_run(tmp_path):
     for j, t in enumerate((0.3, 0.0, 0.15)):
         ph = np.exp(1j * klist[0] @ cell.a[j])
         np.testing.assert_allclose(ph, np.exp(2j * np.pi * t) * np.ones(len(ph)), atol=1e-12)
+
+
+def test_device_widths_keep_the_reference_residual_pattern():
+    """deepsolid_amd/device.py::device_widths: the widths the kernels run for the reference's hidden_dims (zero-padded weights, exact).
+    One-electron widths become multiples of 64, pair widths 16 or 32, and two consecutive padded widths are equal exactly where
+    the reference's are (network.py:525-528 adds a residual when in == out; the library reads that off the widths it is given)."""
+    import itertools
+    from deepsolid_amd.device import device_widths
+    assert device_widths(((256, 32),) * 3, 4) == ((256, 32),) * 3
+    assert device_widths(((100, 20),) * 3, 4) == ((128, 32),) * 3
+    assert device_widths(((100, 10), (120, 12), (120, 12)), 4) == ((128, 16), (192, 32), (192, 32))
+    assert device_widths(((64, 16), (64, 16)), 64) == ((64, 16), (64, 16))          # the input width itself is 64: a residual at layer 0
+    assert device_widths(((64, 16), (64, 16)), 62) == ((128, 16), (128, 16))        # 62 input rows pad to 64, but 62 != 64: none
+    assert device_widths(((256, 32), (256, 32), (256, 24)), 4, n_double=2) == ((256, 32),) * 3      # the last pair width is unused
+    with pytest.raises(ValueError):
+        device_widths(((64, 20), (64, 24), (64, 24)), 4)       # 20 -> 24 without a residual, both need the 32-wide kernels
+    with pytest.raises(ValueError):
+        device_widths(((64, 40), (64, 40)), 4)                 # pair widths beyond 32
+    singles, pairs = (40, 64, 100, 128, 130), (8, 16, 20, 32)
+    for dims in itertools.product(itertools.product(singles, pairs), repeat=3):
+        try:
+            dev = device_widths(dims, 4)
+        except ValueError:
+            continue
+        for l, ((a, b), (pa, pb)) in enumerate(zip(dims, dev)):
+            assert pa % 64 == 0 and pa >= a and pb in (16, 32) and pb >= b
+            if l:
+                assert (a == dims[l - 1][0]) == (pa == dev[l - 1][0])
+                assert (b == dims[l - 1][1]) == (pb == dev[l - 1][1])
