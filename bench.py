@@ -210,6 +210,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend ('nccl' is RCCL on ROCm; 'gloo' only for the launcher test on CPU hosts)")
+    ap.add_argument('--shared-gpu', action='store_true',
+                    help='every rank uses device 0 (with --backend gloo: the N > 1 path exercised on a one-GPU box; not a scaling number)')
     ap.add_argument('--single-scaling', action='store_true', help='N > 1: measure only --scaling, not the other mode beside it')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / reduction plumbing only (no GPU work): every rank reports in, rank 0 prints the JSON line')
@@ -226,7 +228,7 @@ def main():
         if args.batch % world:
             raise SystemExit(f'--scaling strong: batch {args.batch} is not divisible by {world} ranks (process.py:75)')
         args.batch = args.batch // world
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = 0 if args.shared_gpu else int(os.environ.get('LOCAL_RANK', 0))
     import torch.distributed as dist
     use_dist = world > 1 or 'RANK' in os.environ          # launched by torchrun: one process per GPU over RCCL
     if args.dry_run:
@@ -236,7 +238,10 @@ def main():
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group(args.backend, device_id=dev)
+        if args.backend == 'gloo':
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group(args.backend, device_id=dev)
 
     from deepsolid_amd import network, systems, train
     dtype = torch.float64 if args.dtype == 'f64' else torch.float32
