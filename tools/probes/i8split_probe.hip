@@ -15,6 +15,7 @@
 // Built as a shared library for tools/i8probe.py (ctypes); not part of the product library.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -23,7 +24,8 @@ namespace {
 constexpr int NPL = 6;            // digit planes
 constexpr int FB = 47;            // fractional bits
 constexpr int P = 80, ST = 5;     // jet slots (5 tiles of 16)
-constexpr int CH16 = NPL * 4 * P; // 16-byte pieces per chunk (1920 = 30720 bytes)
+constexpr int CH16 = NPL * 4 * P; // 16-byte pieces of a chunk's planes (1920 = 30720 bytes)
+constexpr int CHI = (CH16 + P / 2 + 63) / 64 * 64;   // ... of a chunk image: planes + 80 column scales, in whole 1 KB pieces (1984)
 
 __device__ __forceinline__ int exp_for(double m) {
     // e with |x| 2^-e <= 0.5 for every |x| <= m
@@ -61,20 +63,24 @@ __global__ void k_prep_w(const double* __restrict__ W, int K, int Nout, uint8_t*
         for (int p = 0; p < NPL; ++p) {
             const int byte = 5 - p;
             const uint8_t v = byte < 4 ? (uint8_t)(lo >> (8 * byte)) : (uint8_t)(hi >> (8 * (byte - 4)));
-            WP[(((((size_t)c * NPL + p) * (Nout / 16) + (n >> 4)) * 4 + kq) * 16 + (n & 15)) * 16 + b] = v;
+            // fragment row rho = 4 lq + r hands its result to accumulator register r of lane group lq; feature n % 16 = lq + 4 r sits
+            // there, so that the output tile has the float64 MFMA's layout (ds_device.h acc_row<double>) and its epilogues apply
+            const int f = n & 15, rho = 4 * (f & 3) + (f >> 2);
+            WP[(((((size_t)c * NPL + p) * (Nout / 16) + (n >> 4)) * 4 + kq) * 16 + rho) * 16 + b] = v;
         }
     }
     (void)nch;
 }
 
-// ---- jets: X[tile][ldk rows][P] -> XP[tile][chunk][plane][k quarter][slot][16 bytes], XS[tile][chunk][slot] = 2^(e - 15)
+// ---- jets: X[tile][ldk rows][P] -> chunk images XP[tile][chunk]{[plane][k quarter][slot][16 bytes] | scales[slot] = 2^(e - 15) | pad}
+// (CHI 16-byte pieces per chunk: planes, then the 80 column scales as doubles, padded to whole 1 KB wave pieces)
 // one workgroup of 320 threads per (tile, chunk): thread = (k quarter, slot)
-__global__ void __launch_bounds__(320) k_slice(const double* __restrict__ X, size_t tile_stride, int nch, uint4* __restrict__ XP,
-                                               double* __restrict__ XS) {
+__global__ void __launch_bounds__(320) k_slice(const double* __restrict__ X, size_t tile_stride, int nch, uint4* __restrict__ XP) {
     __shared__ double mx[4][P];
     const int c = blockIdx.x, tile = blockIdx.y;
     const int kq = threadIdx.x / P, slot = threadIdx.x % P;
     const double* xp = X + (size_t)tile * tile_stride + (size_t)(64 * c + 16 * kq) * P + slot;
+    uint4* img = XP + ((size_t)tile * nch + c) * CHI;
     double v[16], m = 0;
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
@@ -85,7 +91,7 @@ __global__ void __launch_bounds__(320) k_slice(const double* __restrict__ X, siz
     __syncthreads();
     m = fmax(fmax(mx[0][slot], mx[1][slot]), fmax(mx[2][slot], mx[3][slot]));
     const int e = exp_for(m);
-    if (kq == 0) XS[((size_t)tile * nch + c) * P + slot] = ldexp(1.0, e - 15);
+    if (kq == 0) reinterpret_cast<double*>(img + CH16)[slot] = ldexp(1.0, e - 15);
     const double sc = ldexp(1.0, FB - e);
     uint32_t lo[16], hi[16];
 #pragma unroll
@@ -104,118 +110,288 @@ __global__ void __launch_bounds__(320) k_slice(const double* __restrict__ X, siz
             }
             w[q] = r;
         }
-        XP[((((size_t)tile * nch + c) * NPL + p) * 4 + kq) * P + slot] = make_uint4(w[0], w[1], w[2], w[3]);
+        img[(p * 4 + kq) * P + slot] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
-// ---- the contraction.  grid.x = ntiles * Nout / 64 (workgroup ids b, b + 8, ... share an XCD: the Nout / 64 feature blocks of one
-// electron tile are dealt to one XCD back to back, so the tile's planes are fetched from memory once)
-template <int S0, int NS>
-__device__ __forceinline__ void chunk_half(const v4i (&a)[NPL], const uint4* buf, int lq, int lr, const double* __restrict__ xs,
-                                           double (&zacc)[ST][4]) {
-    v4i acc[NPL][NS];
-#pragma unroll
-    for (int g = 0; g < NPL; ++g)
-#pragma unroll
-        for (int s = 0; s < NS; ++s) acc[g][s] = v4i{0, 0, 0, 0};
-    double sx[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) sx[s] = xs[16 * (S0 + s) + lr];
+// ---- the contraction (second form).  One persistent workgroup of 8 waves per CU walks electron tiles t = blockIdx.x, + gridDim.x, ...;
+// wave w owns output features 16 w .. + 15 and 128 + 16 w .. + 15 (two passes over every chunk, so that one chunk image in LDS
+// serves all 256 features of the tile: the global -> LDS path sustains ~10 bytes per clock and CU, a quarter of what 64 features per
+// image would ask for).  The work of a wave is one stream of bursts (chunk, pass, slot tile): 21 MFMAs on the six group accumulators
+// of ONE 16 x 16 output tile, while the previous burst's accumulators are recombined into float64 on the vector ALU.
+// MODE (timing experiments, wrong results): 1 no stores, 2 no global -> LDS traffic after the first chunk, 8 no recombination,
+// 16 no MFMA
+__device__ __forceinline__ v4i ld_frag(const uint4* p) {
+    const uint4 t = *p;
+    return v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+}
+
+// 21 MFMAs on one 16 x 16 output tile; the B planes come from LDS one plane ahead of their products (bq = the tile's plane 0)
+template <int MODE>
+__device__ __forceinline__ void burst(const v4i (&a)[NPL], const uint4* bq, v4i (&acc)[NPL]) {
+    v4i bf[2];
+    bf[0] = ld_frag(bq);
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
-        v4i bf[NS];
+        if (j + 1 < NPL) bf[(j + 1) & 1] = ld_frag(bq + (j + 1) * 4 * P);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const uint4 t = buf[(j * 4 + lq) * P + 16 * (S0 + s) + lr];
-            bf[s] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        for (int i = 0; i < NPL - j; ++i) {
+            if (MODE & 16) { acc[i + j] = j == 0 ? a[i] + bf[j & 1] : acc[i + j] + bf[j & 1]; continue; }
+            acc[i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], bf[j & 1], j == 0 ? v4i{0, 0, 0, 0} : acc[i + j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < NPL - j; ++i)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) acc[i + j][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], bf[s], acc[i + j][s], 0, 0, 0);
     }
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m1 = (acc[0][s][r] << 8) + acc[1][s][r];
-            const int m2 = (acc[2][s][r] << 8) + acc[3][s][r];
-            const int m3 = (acc[4][s][r] << 8) + acc[5][s][r];
-            double u = (double)m1;
-            u = fma((double)m2, 0x1p-16, u);
-            u = fma((double)m3, 0x1p-32, u);
-            zacc[S0 + s][r] = fma(u, sx[s], zacc[S0 + s][r]);
-        }
 }
 
-template <int NCH>
-__global__ void __launch_bounds__(256, 2) k_i8_gemm(const uint4* __restrict__ XP, const double* __restrict__ XS, const uint4* __restrict__ WP,
-                                                    const double* __restrict__ SW, double* __restrict__ Z, int ntiles, int Nout) {
-    extern __shared__ uint4 smem[];
-    const int nfb = Nout / 64, nf16 = Nout / 16;
-    int tile, fb;
-    {
-        const unsigned b = blockIdx.x;
-        if ((ntiles & 7) == 0) {
-            const unsigned x = b & 7, q = b >> 3;
-            tile = (int)(q / nfb) * 8 + (int)x;
-            fb = (int)(q % nfb);
-        } else {
-            tile = (int)(b / nfb);
-            fb = (int)(b % nfb);
-        }
-    }
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lq = lane >> 4, lr = lane & 15;
-    const int f16 = fb * 4 + wave;
-    const uint4* xp = XP + (size_t)tile * NCH * CH16;
-    const double* xs = XS + (size_t)tile * NCH * P;
-    auto a_ptr = [&](int c, int p) { return WP + ((((size_t)c * NPL + p) * nf16 + f16) * 4 + lq) * 16 + lr; };
-    for (int i = tid; i < CH16; i += 256) smem[i] = xp[i];
-    v4i a[NPL];
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-        const uint4 t = *a_ptr(0, p);
-        a[p] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-    }
-    double zacc[ST][4];
-#pragma unroll
-    for (int s = 0; s < ST; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) zacc[s][r] = 0;
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        __syncthreads();
-        v4i an[NPL];
-        const bool more = c + 1 < NCH;
-        if (more) {
-            // next chunk: global -> LDS without passing registers (1 KB per wave instruction; the destination is wave-uniform
-            // base + lane x 16, which is the planes' own order); it has landed before the barrier that opens chunk c + 1
-            const uint4* src = xp + (size_t)(c + 1) * CH16 + lane;
-            uint4* dst = smem + ((c + 1) & 1) * CH16;
-            for (int pc = wave; pc < CH16 / 64; pc += 4)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * pc),
-                                                 (__attribute__((address_space(3))) void*)(dst + 64 * pc), 16, 0, 0);
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) {
-                const uint4 t = *a_ptr(c + 1, p);
-                an[p] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-            }
-        }
-        const uint4* buf = smem + (c & 1) * CH16;
-        chunk_half<0, 3>(a, buf, lq, lr, xs + c * P, zacc);
-        chunk_half<3, 2>(a, buf, lq, lr, xs + c * P, zacc);
-        if (more) {
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) a[p] = an[p];
-        }
-    }
-    // rows n = 16 f16 + 4 lq + r, slots 16 s + lr
-    double* zp = Z + ((size_t)tile * Nout + 16 * f16 + 4 * lq) * P + lr;
+template <int MODE>
+__device__ __forceinline__ void recombine(const v4i (&acc)[NPL], double sx, double (&z)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const double sw = SW[16 * f16 + 4 * lq + r];
+        if (MODE & 8) { z[r] += (double)(acc[0][r] ^ acc[1][r] ^ acc[2][r] ^ acc[3][r] ^ acc[4][r] ^ acc[5][r]) * sx; continue; }
+        const int m1 = (acc[0][r] << 8) + acc[1][r];
+        const int m2 = (acc[2][r] << 8) + acc[3][r];
+        const int m3 = (acc[4][r] << 8) + acc[5][r];
+        double u = (double)m1;
+        u = fma((double)m2, 0x1p-16, u);
+        u = fma((double)m3, 0x1p-32, u);
+        z[r] = fma(u, sx, z[r]);
+    }
+}
+
+template <int NCH, int MODE>
+__global__ void __launch_bounds__(512, 1) k_i8_gemm(const uint4* __restrict__ XP, const uint4* __restrict__ WP, const double* __restrict__ SW,
+                                                    double* __restrict__ Z, int ntiles, int Nout) {
+    extern __shared__ uint4 smem[];
+    const int nf16 = Nout / 16;                  // (= 16: two passes of 8 waves)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lq = lane >> 4, lr = lane & 15;
+    const int n_my = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto a_ptr = [&](int c, int p, int pass) { return WP + ((((size_t)c * NPL + p) * nf16 + wave + 8 * pass) * 4 + lq) * 16 + lr; };
+    // chunk g of this workgroup's stream -> LDS buffer g & 1 (1 KB per wave instruction, destination = wave-uniform base + lane x 16)
+    auto stage = [&](int g) {
+        const int tile = (int)blockIdx.x + (g / NCH) * (int)gridDim.x, c = g % NCH;
+        const uint4* src = XP + ((size_t)tile * NCH + c) * CHI + lane;
+        uint4* dst = smem + (g & 1) * CHI;
 #pragma unroll
-        for (int s = 0; s < ST; ++s) __builtin_nontemporal_store(zacc[s][r] * sw, &zp[(size_t)r * P + 16 * s]);
+        for (int u = 0; u < (CHI / 64 + 7) / 8; ++u) {
+            const int pc = wave + 8 * u;
+            if (pc < CHI / 64)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * pc),
+                                                 (__attribute__((address_space(3))) void*)(dst + 64 * pc), 16, 0, 0);
+        }
+    };
+    if (n_my <= 0) return;
+    stage(0);
+    v4i aw[2][NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) aw[0][p] = ld_frag(a_ptr(0, p, 0));
+    v4i accs[2][NPL];
+#pragma unroll
+    for (int g = 0; g < NPL; ++g) accs[1][g] = v4i{0, 0, 0, 0};
+    double sx_prev = 0;
+    double zacc[2][ST][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < ST; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zacc[q][s][r] = 0;
+    const int n_chunks = n_my * NCH;
+    int g = 0;
+#pragma unroll 1
+    for (int it = 0; it < n_my; ++it) {
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c, ++g) {
+            __syncthreads();         // chunk g has landed (vmcnt drained in front of the barrier), buffer (g + 1) & 1 is free
+            if (g + 1 < n_chunks && !(MODE & 2)) stage(g + 1);
+            const uint4* buf = smem + ((MODE & 2) ? 0 : (g & 1)) * CHI;
+            const uint4* bp = buf + lq * P + lr;
+            const double* sxp = reinterpret_cast<const double*>(buf + CH16) + lr;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                // the other pass's weight digits arrive while this pass computes: pass 1 of this chunk, then pass 0 of the next
+                {
+                    const int cn = pass == 0 ? c : (c + 1 < NCH ? c + 1 : 0);
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) aw[pass ^ 1][p] = ld_frag(a_ptr(cn, p, pass ^ 1));
+                }
+#pragma unroll
+                for (int t = 0; t < ST; ++t) {
+                    const int b = pass * ST + t;
+                    const double sx = sxp[16 * t];
+                    burst<MODE>(aw[pass], bp + 16 * t, accs[b & 1]);
+                    // the previous burst's tile: (pass, t - 1), (0, 4) for b = 5, (1, 4) of the previous chunk for b = 0
+                    recombine<MODE>(accs[(b & 1) ^ 1], sx_prev, zacc[b == 0 ? 1 : (t == 0 ? 0 : pass)][t == 0 ? ST - 1 : t - 1]);
+                    sx_prev = sx;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // end of tile: flush the last burst, scale by the weight columns' factors, store, start over
+        recombine<MODE>(accs[1], sx_prev, zacc[1][ST - 1]);
+        sx_prev = 0;
+        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = 16 * (wave + 8 * q) + lq;             // rows n + 4 r, slots 16 s + lr
+            double* zp = Z + ((size_t)tile * Nout + n) * P + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double sw = SW[n + 4 * r];
+#pragma unroll
+                for (int s = 0; s < ST; ++s) {
+                    const double o = zacc[q][s][r] * sw;
+                    if (!(MODE & 1) || o == 1.2345e-300) __builtin_nontemporal_store(o, &zp[(size_t)(4 * r) * P + 16 * s]);
+                    zacc[q][s][r] = 0;
+                }
+            }
+        }
+    }
+}
+
+// ---- third form: the layer kernel's own input.  The float64 tile is the input (no pre-sliced planes in memory): every 64-row
+// chunk lands in LDS as it is (global -> LDS, 40 KB), 320 threads cut it into the digit planes of the one LDS image the MFMA bursts
+// read, the weight digits stream through registers.  Wave w owns output features 32 w .. + 31 (two passes of 16), rows placed like
+// the float64 MFMA's accumulator (lane group + 4 x register).
+template <int NCH, int MODE>
+__global__ void __launch_bounds__(512, 1) k_i8_layer(const double* __restrict__ X, size_t tile_stride, const uint4* __restrict__ WP,
+                                                     const double* __restrict__ SW, double* __restrict__ Z, int ntiles, int Nout,
+                                                     unsigned long long* clk) {
+    // MODE & 32: wave 0 and wave 5 of every workgroup add their shader cycles per phase to clk[8 * (wave != 0) + ...]:
+    // 0 total, 1 100 MHz ticks, 2 waiting at the chunk's first barrier, 3 slicing phase (incl. its barriers), 4 bursts, 5 tile epilogue
+    long long tk0 = 0, tr0 = 0, t_bar = 0, t_slice = 0, t_burst = 0, t_epi = 0, ts = 0;
+    auto tick = [&](long long& acc) { if (MODE & 32) { const long long n = clock64(); acc += n - ts; ts = n; } };
+    if (MODE & 32) { tk0 = clock64(); tr0 = wall_clock64(); ts = tk0; }
+    extern __shared__ uint4 smem[];
+    uint4* PL = smem;                                             // CHI pieces: planes + column scales
+    double* R = reinterpret_cast<double*>(smem + CHI);            // 64 x 80 raw rows
+    double* MX = R + 64 * P;                                      // [4][80] partial column maxima
+    const int nf16 = Nout / 16;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lq = lane >> 4, lr = lane & 15;
+    const int n_my = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto a_ptr = [&](int c, int p, int pass) { return WP + ((((size_t)c * NPL + p) * nf16 + 2 * wave + pass) * 4 + lq) * 16 + lr; };
+    auto stage = [&](int g) {                                     // raw rows of chunk g of the stream -> R (5 x 1 KB per wave)
+        const int tile = (int)blockIdx.x + (g / NCH) * (int)gridDim.x, c = g % NCH;
+        const uint4* src = reinterpret_cast<const uint4*>(X + (size_t)tile * tile_stride + (size_t)c * 64 * P) + lane;
+        uint4* dst = reinterpret_cast<uint4*>(R);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int pc = wave + 8 * u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * pc),
+                                             (__attribute__((address_space(3))) void*)(dst + 64 * pc), 16, 0, 0);
+        }
+    };
+    if (n_my <= 0) return;
+    stage(0);
+    v4i aw[2][NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) aw[0][p] = ld_frag(a_ptr(0, p, 0));
+    v4i accs[2][NPL];
+#pragma unroll
+    for (int g = 0; g < NPL; ++g) accs[1][g] = v4i{0, 0, 0, 0};
+    double sx_prev = 0;
+    double zacc[2][ST][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < ST; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zacc[q][s][r] = 0;
+    const int n_chunks = n_my * NCH;
+    int g = 0;
+#pragma unroll 1
+    for (int it = 0; it < n_my; ++it) {
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c, ++g) {
+            tick(t_burst);
+            __syncthreads();         // the raw rows of chunk g have landed; every wave is through with the planes of chunk g - 1
+            tick(t_bar);
+            if (!(MODE & 4) || g == 0) {
+                const int kq = tid / P, slot = tid % P;
+                if (tid < 4 * P) {
+                    double m = 0;
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) m = fmax(m, fabs(R[(16 * kq + b) * P + slot]));
+                    MX[kq * P + slot] = m;
+                }
+                __syncthreads();
+                if (tid < 4 * P) {
+                    const double m = fmax(fmax(MX[slot], MX[P + slot]), fmax(MX[2 * P + slot], MX[3 * P + slot]));
+                    const int e = exp_for(m);
+                    if (kq == 0) reinterpret_cast<double*>(PL + CH16)[slot] = ldexp(1.0, e - 15);
+                    const double sc = ldexp(1.0, FB - e);
+                    // (the rows are read again rather than kept in registers across the barrier)
+                    uint32_t w[NPL][4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t lo[4], hi[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) digits6(R[(16 * kq + 4 * q + b) * P + slot], sc, lo[b], hi[b]);
+#pragma unroll
+                        for (int p = 0; p < NPL; ++p) {
+                            // plane p = byte 5 - p of the 48-bit values: bytes 0..3 of lo, 0..1 of hi
+                            const uint32_t* src = p >= 2 ? lo : hi;
+                            const int byte = p >= 2 ? 5 - p : 1 - p;
+                            const uint32_t sel01 = 0x0c0c0000u | ((4 + byte) << 8) | byte;      // v_perm: (src1 byte, src0 byte) -> low half
+                            const uint32_t x01 = __builtin_amdgcn_perm(src[1], src[0], sel01);
+                            const uint32_t x23 = __builtin_amdgcn_perm(src[3], src[2], sel01);
+                            w[p][q] = x01 | (x23 << 16);
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) PL[(p * 4 + kq) * P + slot] = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
+                }
+                __syncthreads();     // planes of chunk g are in place, R is free
+            }
+            tick(t_slice);
+            if (g + 1 < n_chunks && !(MODE & 2)) stage(g + 1);
+            const uint4* bp = PL + lq * P + lr;
+            const double* sxp = reinterpret_cast<const double*>(PL + CH16) + lr;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                {
+                    const int cn = pass == 0 ? c : (c + 1 < NCH ? c + 1 : 0);
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) aw[pass ^ 1][p] = ld_frag(a_ptr(cn, p, pass ^ 1));
+                }
+#pragma unroll
+                for (int t = 0; t < ST; ++t) {
+                    const int b = pass * ST + t;
+                    const double sx = sxp[16 * t];
+                    burst<MODE>(aw[pass], bp + 16 * t, accs[b & 1]);
+                    recombine<MODE>(accs[(b & 1) ^ 1], sx_prev, zacc[b == 0 ? 1 : (t == 0 ? 0 : pass)][t == 0 ? ST - 1 : t - 1]);
+                    sx_prev = sx;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        tick(t_burst);
+        recombine<MODE>(accs[1], sx_prev, zacc[1][ST - 1]);
+        sx_prev = 0;
+        const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = 16 * (2 * wave + q) + lq;             // rows n + 4 r, slots 16 s + lr
+            double* zp = Z + ((size_t)tile * Nout + n) * P + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double sw = SW[n + 4 * r];
+#pragma unroll
+                for (int s = 0; s < ST; ++s) {
+                    const double o = zacc[q][s][r] * sw;
+                    if (!(MODE & 1) || o == 1.2345e-300) __builtin_nontemporal_store(o, &zp[(size_t)(4 * r) * P + 16 * s]);
+                    zacc[q][s][r] = 0;
+                }
+            }
+        }
+        tick(t_epi);
+    }
+    if ((MODE & 32) && lane == 0 && (wave == 0 || wave == 5)) {
+        unsigned long long* o = clk + (wave == 0 ? 0 : 8);
+        atomicAdd(&o[0], (unsigned long long)(clock64() - tk0));
+        atomicAdd(&o[1], (unsigned long long)(wall_clock64() - tr0));
+        atomicAdd(&o[2], (unsigned long long)t_bar);
+        atomicAdd(&o[3], (unsigned long long)t_slice);
+        atomicAdd(&o[4], (unsigned long long)t_burst);
+        atomicAdd(&o[5], (unsigned long long)t_epi);
     }
 }
 
@@ -234,13 +410,82 @@ __global__ void k_ref(const double* __restrict__ X, size_t tile_stride, const do
     ZA[((size_t)tile * Nout + n) * P + slot] = sa;
 }
 
+// ---- rate of v_mfma_i32_16x16x64_i8 by itself: every wave issues `iters` rounds of NACC independent MFMAs (no memory traffic);
+// out[0] += shader cycles, out[1] += 100 MHz ticks of wave 0 of every workgroup
+template <int NACC>
+__global__ void __launch_bounds__(512, 1) k_i8_rate(int iters, unsigned long long* out, int* sink) {
+    v4i acc[NACC];
+    const v4i a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, (int)blockIdx.x, 7};
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = v4i{0, 0, 0, 0};
+    const long long c0 = clock64(), r0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc[i], 0, 0, 0);
+    }
+    const long long c1 = clock64(), r1 = wall_clock64();
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) t += acc[i][0] + acc[i][3];
+    if (t == 0x7fffffff) sink[0] = t;
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], (unsigned long long)(c1 - c0));
+        atomicAdd(&out[1], (unsigned long long)(r1 - r0));
+    }
+}
+
+// ---- the 21-product burst by itself (operands in registers, no memory): ORDER 0 = groups ascending within a round (the kernel's
+// source order), 1 = descending (the longest chain first), 2 = two independent tiles interleaved
+template <int ORDER>
+__global__ void __launch_bounds__(512, 1) k_i8_burst_rate(int iters, unsigned long long* out, int* sink) {
+    v4i a[NPL], b[NPL], acc[2][NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        a[i] = v4i{(int)threadIdx.x, i, 2, 3};
+        b[i] = v4i{4, 5, (int)blockIdx.x, i};
+        acc[0][i] = acc[1][i] = v4i{0, 0, 0, 0};
+    }
+    int t = 0;
+    const long long c0 = clock64(), r0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            if (ORDER == 0) {
+#pragma unroll
+                for (int i = 0; i < NPL - j; ++i)
+                    acc[0][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], j == 0 ? v4i{0, 0, 0, 0} : acc[0][i + j], 0, 0, 0);
+            } else if (ORDER == 1) {
+#pragma unroll
+                for (int i = NPL - j - 1; i >= 0; --i)
+                    acc[0][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], j == 0 ? v4i{0, 0, 0, 0} : acc[0][i + j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = NPL - j - 1; i >= 0; --i) {
+                    acc[0][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], j == 0 ? v4i{0, 0, 0, 0} : acc[0][i + j], 0, 0, 0);
+                    acc[1][i + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b[i], a[j], j == 0 ? v4i{0, 0, 0, 0} : acc[1][i + j], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) t ^= acc[0][i][0] ^ (ORDER == 2 ? acc[1][i][1] : 0);
+        a[0][1] = t & 1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const long long c1 = clock64(), r1 = wall_clock64();
+    if (t == 0x7fffffff) sink[0] = t;
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], (unsigned long long)(c1 - c0));
+        atomicAdd(&out[1], (unsigned long long)(r1 - r0));
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-// bytes of the digit planes / scales of n tiles with K rows
-int64_t i8p_xp_bytes(int64_t ntiles, int K) { return ntiles * (K / 64) * (int64_t)CH16 * 16; }
-int64_t i8p_xs_bytes(int64_t ntiles, int K) { return ntiles * (K / 64) * (int64_t)P * 8; }
+// bytes of the chunk images of n tiles with K rows
+int64_t i8p_xp_bytes(int64_t ntiles, int K) { return ntiles * (K / 64) * (int64_t)CHI * 16; }
 int64_t i8p_wp_bytes(int K, int Nout) { return (int64_t)K * Nout * NPL; }
 
 int i8p_prep_w(const double* W, int K, int Nout, void* WP, double* SW, void* stream) {
@@ -249,19 +494,55 @@ int i8p_prep_w(const double* W, int K, int Nout, void* WP, double* SW, void* str
     return hipGetLastError() != hipSuccess;
 }
 
-int i8p_slice(const double* X, int64_t ntiles, int64_t tile_stride, int K, void* XP, double* XS, void* stream) {
+int i8p_slice(const double* X, int64_t ntiles, int64_t tile_stride, int K, void* XP, void* stream) {
     if (K % 64) return 1;
-    hipLaunchKernelGGL(k_slice, dim3(K / 64, (unsigned)ntiles), dim3(320), 0, (hipStream_t)stream, X, (size_t)tile_stride, K / 64, (uint4*)XP, XS);
+    hipLaunchKernelGGL(k_slice, dim3(K / 64, (unsigned)ntiles), dim3(320), 0, (hipStream_t)stream, X, (size_t)tile_stride, K / 64, (uint4*)XP);
     return hipGetLastError() != hipSuccess;
 }
 
-int i8p_gemm(const void* XP, const double* XS, const void* WP, const double* SW, double* Z, int64_t ntiles, int K, int Nout, void* stream) {
-    if (Nout % 64) return 1;
-    const dim3 grid((unsigned)(ntiles * (Nout / 64))), block(256);
-    const size_t sh = 2 * (size_t)CH16 * 16;
+int i8p_gemm(const void* XP, const void* WP, const double* SW, double* Z, int64_t ntiles, int K, int Nout, int mode, void* stream) {
+    if (Nout != 256 || K != 320) return 1;
+    const dim3 grid((unsigned)std::min<int64_t>(ntiles, 256)), block(512);
+    const size_t sh = 2 * (size_t)CHI * 16;
     hipStream_t st = (hipStream_t)stream;
-    if (K == 320) hipLaunchKernelGGL(k_i8_gemm<5>, grid, block, sh, st, (const uint4*)XP, XS, (const uint4*)WP, SW, Z, (int)ntiles, Nout);
-    else if (K == 256) hipLaunchKernelGGL(k_i8_gemm<4>, grid, block, sh, st, (const uint4*)XP, XS, (const uint4*)WP, SW, Z, (int)ntiles, Nout);
+#define I8P_GO(M) case M: hipLaunchKernelGGL((k_i8_gemm<5, M>), grid, block, sh, st, (const uint4*)XP, (const uint4*)WP, SW, Z, (int)ntiles, Nout); break
+    switch (mode) {
+        I8P_GO(0); I8P_GO(1); I8P_GO(2); I8P_GO(3); I8P_GO(8); I8P_GO(11); I8P_GO(16); I8P_GO(19); I8P_GO(27);
+        default: return 1;
+    }
+#undef I8P_GO
+    return hipGetLastError() != hipSuccess;
+}
+
+int i8p_rate(int blocks, int threads, int iters, int nacc, unsigned long long* out, int* sink, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (nacc == 4) hipLaunchKernelGGL(k_i8_rate<4>, dim3(blocks), dim3(threads), 0, st, iters, out, sink);
+    else if (nacc == 8) hipLaunchKernelGGL(k_i8_rate<8>, dim3(blocks), dim3(threads), 0, st, iters, out, sink);
+    else if (nacc == 16) hipLaunchKernelGGL(k_i8_rate<16>, dim3(blocks), dim3(threads), 0, st, iters, out, sink);
+    else return 1;
+    return hipGetLastError() != hipSuccess;
+}
+
+int i8p_layer(const double* X, int64_t tile_stride, const void* WP, const double* SW, double* Z, int64_t ntiles, int K, int Nout, int mode,
+              unsigned long long* clk, void* stream) {
+    if (Nout != 256 || K != 320) return 1;
+    const dim3 grid((unsigned)std::min<int64_t>(ntiles, 256)), block(512);
+    const size_t sh = (size_t)CHI * 16 + 64 * P * 8 + 4 * P * 8;
+    hipStream_t st = (hipStream_t)stream;
+#define I8P_GO(M) case M: hipLaunchKernelGGL((k_i8_layer<5, M>), grid, block, sh, st, X, (size_t)tile_stride, (const uint4*)WP, SW, Z, (int)ntiles, Nout, clk); break
+    switch (mode) {
+        I8P_GO(0); I8P_GO(1); I8P_GO(2); I8P_GO(3); I8P_GO(4); I8P_GO(7); I8P_GO(8); I8P_GO(15); I8P_GO(16); I8P_GO(32); I8P_GO(39); I8P_GO(47);
+        default: return 1;
+    }
+#undef I8P_GO
+    return hipGetLastError() != hipSuccess;
+}
+
+int i8p_burst_rate(int blocks, int threads, int iters, int order, unsigned long long* out, int* sink, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (order == 0) hipLaunchKernelGGL(k_i8_burst_rate<0>, dim3(blocks), dim3(threads), 0, st, iters, out, sink);
+    else if (order == 1) hipLaunchKernelGGL(k_i8_burst_rate<1>, dim3(blocks), dim3(threads), 0, st, iters, out, sink);
+    else if (order == 2) hipLaunchKernelGGL(k_i8_burst_rate<2>, dim3(blocks), dim3(threads), 0, st, iters, out, sink);
     else return 1;
     return hipGetLastError() != hipSuccess;
 }
