@@ -248,39 +248,90 @@ __global__ void __launch_bounds__(512, 1) k_i8_gemm(const uint4* __restrict__ XP
 }
 
 // ---- third form: the layer kernel's own input.  The float64 tile is the input (no pre-sliced planes in memory): every 64-row
-// chunk lands in LDS as it is (global -> LDS, 40 KB), 320 threads cut it into the digit planes of the one LDS image the MFMA bursts
-// read, the weight digits stream through registers.  Wave w owns output features 32 w .. + 31 (two passes of 16), rows placed like
-// the float64 MFMA's accumulator (lane group + 4 x register).
+// chunk lands in LDS as it is (global -> LDS, 40 KB, requested one chunk before it is cut), is cut into digit planes for the NEXT
+// chunk's bursts while the current chunk's bursts run, the weight digits stream through registers.  Wave w owns output features
+// 32 w .. + 31 (two passes of 16), rows placed like the float64 MFMA's accumulator (lane group + 4 x register).
+//
+// Column exponents of a chunk, phase A: every wave looks at the 8 raw rows IT brought in (rows 8 w .. 8 w + 7) and folds the high
+// words of |x| into the chunk's 80 column maxima with LDS atomics.  Only the largest EXPONENT matters; a non-finite entry wins the
+// maximum and turns the column's scale -- hence every output of the column -- into NaN.
+__device__ __forceinline__ void chunk_maxima(const double* __restrict__ R, uint32_t* __restrict__ MXH, int wave, int lane) {
+    const uint32_t* Rh = reinterpret_cast<const uint32_t*>(R) + 1;
+    uint32_t m0 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m0 = max(m0, Rh[((8 * wave + k) * P + lane) * 2] & 0x7fffffffu);
+    const int s1 = 64 + (lane & 15), k1 = 8 * wave + 2 * (lane >> 4);
+    const uint32_t m1 = max(Rh[(k1 * P + s1) * 2] & 0x7fffffffu, Rh[((k1 + 1) * P + s1) * 2] & 0x7fffffffu);
+    atomicMax(&MXH[lane], m0);
+    atomicMax(&MXH[s1], m1);
+}
+
+// phase B: item = (k quarter, slot) -> the six 16-byte pieces of its 16 rows, and (k quarter 0) the column's scale 2^(e - 15)
+__device__ __forceinline__ void slice_chunk(const double* __restrict__ R, const uint32_t* __restrict__ MXH, uint4* __restrict__ PL, int item) {
+    const int kq = item / P, slot = item % P;
+    const int field = (int)(MXH[slot] >> 20);
+    const int e = max(field, 122) - 1021;             // |x| < 2^(field - 1022) = 2^(e - 1): |x| 2^-e < 0.5
+    if (kq == 0)
+        reinterpret_cast<double*>(PL + CH16)[slot] = field == 0x7ff ? __longlong_as_double(0x7ff8000000000000ll) : __hiloint2double((1023 + e - 15) << 20, 0);
+    const double sc = __hiloint2double((1023 + FB - e) << 20, 0);
+    uint32_t* PLw = reinterpret_cast<uint32_t*>(PL);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        double v[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v[b] = R[(16 * kq + 8 * h + b) * P + slot];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) digits6(v[4 * q2 + b], sc, lo[b], hi[b]);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                // plane p = byte 5 - p of the 48-bit values: bytes 0..3 of lo, 0..1 of hi
+                const uint32_t* src = p >= 2 ? lo : hi;
+                const int byte = p >= 2 ? 5 - p : 1 - p;
+                const uint32_t sel01 = 0x0c0c0000u | ((4 + byte) << 8) | byte;      // v_perm: (src1 byte, src0 byte) -> low half
+                const uint32_t x01 = __builtin_amdgcn_perm(src[1], src[0], sel01);
+                const uint32_t x23 = __builtin_amdgcn_perm(src[3], src[2], sel01);
+                PLw[((p * 4 + kq) * P + slot) * 4 + 2 * h + q2] = x01 | (x23 << 16);      // (a dword at a time: no staging of the pieces)
+            }
+        }
+    }
+}
+
 template <int NCH, int MODE>
 __global__ void __launch_bounds__(512, 1) k_i8_layer(const double* __restrict__ X, size_t tile_stride, const uint4* __restrict__ WP,
                                                      const double* __restrict__ SW, double* __restrict__ Z, int ntiles, int Nout,
                                                      unsigned long long* clk) {
     // MODE & 32: wave 0 and wave 5 of every workgroup add their shader cycles per phase to clk[8 * (wave != 0) + ...]:
-    // 0 total, 1 100 MHz ticks, 2 waiting at the chunk's first barrier, 3 slicing phase (incl. its barriers), 4 bursts, 5 tile epilogue
+    // 0 total, 1 100 MHz ticks, 2 waiting at the chunk's barrier, 3 slicing (both phases and their barrier), 4 bursts, 5 tile epilogue
     long long tk0 = 0, tr0 = 0, t_bar = 0, t_slice = 0, t_burst = 0, t_epi = 0, ts = 0;
     auto tick = [&](long long& acc) { if (MODE & 32) { const long long n = clock64(); acc += n - ts; ts = n; } };
     if (MODE & 32) { tk0 = clock64(); tr0 = wall_clock64(); ts = tk0; }
     extern __shared__ uint4 smem[];
-    uint4* PL = smem;                                             // CHI pieces: planes + column scales
-    double* R = reinterpret_cast<double*>(smem + CHI);            // 64 x 80 raw rows
-    double* MX = R + 64 * P;                                      // [4][80] partial column maxima
+    uint4* const PLb = smem;                                                  // 2 x CHI pieces: planes + column scales
+    double* const Rb = reinterpret_cast<double*>(smem + 2 * CHI);             // 2 x (64 x 80) raw rows
+    uint32_t* const MXb = reinterpret_cast<uint32_t*>(Rb + 2 * 64 * P);       // 2 x 80 column maxima (high words)
     const int nf16 = Nout / 16;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lq = lane >> 4, lr = lane & 15;
     const int n_my = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto a_ptr = [&](int c, int p, int pass) { return WP + ((((size_t)c * NPL + p) * nf16 + 2 * wave + pass) * 4 + lq) * 16 + lr; };
-    auto stage = [&](int g) {                                     // raw rows of chunk g of the stream -> R (5 x 1 KB per wave)
+    auto stage = [&](int g) {                 // raw rows of chunk g of the stream -> R[g & 1]: wave w brings rows 8 w .. 8 w + 7 (5 x 1 KB)
         const int tile = (int)blockIdx.x + (g / NCH) * (int)gridDim.x, c = g % NCH;
         const uint4* src = reinterpret_cast<const uint4*>(X + (size_t)tile * tile_stride + (size_t)c * 64 * P) + lane;
-        uint4* dst = reinterpret_cast<uint4*>(R);
+        uint4* dst = reinterpret_cast<uint4*>(Rb + (g & 1) * 64 * P);
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
-            const int pc = wave + 8 * u;
+            const int pc = 5 * wave + u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * pc),
                                              (__attribute__((address_space(3))) void*)(dst + 64 * pc), 16, 0, 0);
         }
     };
     if (n_my <= 0) return;
+    const int n_chunks = n_my * NCH;
+    if (tid < 2 * P) MXb[tid] = 0;
     stage(0);
+    if (n_chunks > 1) stage(1);
     v4i aw[2][NPL];
 #pragma unroll
     for (int p = 0; p < NPL; ++p) aw[0][p] = ld_frag(a_ptr(0, p, 0));
@@ -295,54 +346,31 @@ __global__ void __launch_bounds__(512, 1) k_i8_layer(const double* __restrict__ 
         for (int s = 0; s < ST; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) zacc[q][s][r] = 0;
-    const int n_chunks = n_my * NCH;
+    __syncthreads();                 // raw rows of chunks 0 and 1 have landed, the maxima are zero
+    chunk_maxima(Rb, MXb, wave, lane);
+    __syncthreads();
+    if (tid < 4 * P) slice_chunk(Rb, MXb, PLb, tid);
     int g = 0;
 #pragma unroll 1
     for (int it = 0; it < n_my; ++it) {
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c, ++g) {
             tick(t_burst);
-            __syncthreads();         // the raw rows of chunk g have landed; every wave is through with the planes of chunk g - 1
+            __syncthreads();         // planes of chunk g complete, raw rows of chunk g + 1 landed; planes (g + 1) & 1 and raw g & 1 are free
             tick(t_bar);
-            if (!(MODE & 4) || g == 0) {
-                const int kq = tid / P, slot = tid % P;
-                if (tid < 4 * P) {
-                    double m = 0;
-#pragma unroll
-                    for (int b = 0; b < 16; ++b) m = fmax(m, fabs(R[(16 * kq + b) * P + slot]));
-                    MX[kq * P + slot] = m;
-                }
+            if (g + 1 < n_chunks && !(MODE & 4)) {
+                // chunk g + 1 -> digit planes: column maxima (every wave on the 8 rows it brought in), barrier, then 320 (k quarter, slot) items
+                if (tid < P) MXb[(g & 1) * P + tid] = 0;    // (used up; collects for chunk g + 2 after the next chunk barrier)
+                chunk_maxima(Rb + ((g + 1) & 1) * 64 * P, MXb + ((g + 1) & 1) * P, wave, lane);
                 __syncthreads();
-                if (tid < 4 * P) {
-                    const double m = fmax(fmax(MX[slot], MX[P + slot]), fmax(MX[2 * P + slot], MX[3 * P + slot]));
-                    const int e = exp_for(m);
-                    if (kq == 0) reinterpret_cast<double*>(PL + CH16)[slot] = ldexp(1.0, e - 15);
-                    const double sc = ldexp(1.0, FB - e);
-                    // (the rows are read again rather than kept in registers across the barrier)
-                    uint32_t w[NPL][4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t lo[4], hi[4];
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) digits6(R[(16 * kq + 4 * q + b) * P + slot], sc, lo[b], hi[b]);
-#pragma unroll
-                        for (int p = 0; p < NPL; ++p) {
-                            // plane p = byte 5 - p of the 48-bit values: bytes 0..3 of lo, 0..1 of hi
-                            const uint32_t* src = p >= 2 ? lo : hi;
-                            const int byte = p >= 2 ? 5 - p : 1 - p;
-                            const uint32_t sel01 = 0x0c0c0000u | ((4 + byte) << 8) | byte;      // v_perm: (src1 byte, src0 byte) -> low half
-                            const uint32_t x01 = __builtin_amdgcn_perm(src[1], src[0], sel01);
-                            const uint32_t x23 = __builtin_amdgcn_perm(src[3], src[2], sel01);
-                            w[p][q] = x01 | (x23 << 16);
-                        }
-                    }
-#pragma unroll
-                    for (int p = 0; p < NPL; ++p) PL[(p * 4 + kq) * P + slot] = make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]);
-                }
-                __syncthreads();     // planes of chunk g are in place, R is free
             }
-            tick(t_slice);
-            if (g + 1 < n_chunks && !(MODE & 2)) stage(g + 1);
+            // (behind the second barrier: a barrier drains the wave's outstanding global -> LDS loads)
+            if (g + 2 < n_chunks && !(MODE & 2)) stage(g + 2);
+            if (g + 1 < n_chunks && !(MODE & 4)) {
+                if (tid < 4 * P) slice_chunk(Rb + ((g + 1) & 1) * 64 * P, MXb + ((g + 1) & 1) * P, PLb + ((g + 1) & 1) * CHI, tid);
+                tick(t_slice);
+            }
+            const uint4* PL = PLb + ((MODE & 4) ? 0 : (g & 1)) * CHI;
             const uint4* bp = PL + lq * P + lr;
             const double* sxp = reinterpret_cast<const double*>(PL + CH16) + lr;
 #pragma unroll
@@ -527,7 +555,7 @@ int i8p_layer(const double* X, int64_t tile_stride, const void* WP, const double
               unsigned long long* clk, void* stream) {
     if (Nout != 256 || K != 320) return 1;
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, 256)), block(512);
-    const size_t sh = (size_t)CHI * 16 + 64 * P * 8 + 4 * P * 8;
+    const size_t sh = 2 * ((size_t)CHI * 16 + 64 * P * 8) + 2 * P * 4;
     hipStream_t st = (hipStream_t)stream;
 #define I8P_GO(M) case M: hipLaunchKernelGGL((k_i8_layer<5, M>), grid, block, sh, st, X, (size_t)tile_stride, (const uint4*)WP, SW, Z, (int)ntiles, Nout, clk); break
     switch (mode) {
