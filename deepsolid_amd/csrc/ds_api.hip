@@ -3,6 +3,7 @@
 // workspace and launches the kernels of ds_kernels.h on the caller's stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include "ds_grad.h"
 #include "ds_tiles.h"
 #include "ds_mcmc.h"
+#include "ds_i8.h"
 
 // the per-slot-tile-count kernel instances live in ds_tiles_inst.hip (five slot-tile ranges x two element types)
 namespace ds {
@@ -103,6 +105,9 @@ struct ds_system {
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
+    bool use_i8 = true;               // DS_NO_I8 unset: dense hidden layers of the 5-slot-tile float64 cells run their per-electron contraction as an int8 split (ds_i8.h)
+    void* i8_wp = nullptr;            // digit planes of that layer's weights + (behind them) the 256 column scales, refilled at every call
+    int n_cu = 256;                   // compute units of the device (grid of the persistent int8 layer kernel)
     bool use_wide = true;             // DS_NO_WIDE unset: the chunked kernels of ds_wide.h for more than 10 slot tiles where they are faster
     bool wide_all = false;            // DS_WIDE_ALL: ... everywhere (tests, A/B runs)
     int dbg = 0;                      // DS_DBG (kernel development): 32 = phase stamps of one wave; 1 / 2 switch arithmetic off in a `make EXP=1` build only
@@ -534,6 +539,21 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                     hipLaunchKernelGGL((ds::k_layer0_means<T, STC>), dim3(S.nch * nfb * nck, (unsigned)Bc), dim3(256), 0, st, S, c.XL,
                                        (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, blk(s->i_wloc[0]), K0loc, c.ZB, Nout, S.P, c.YO, c.MEAN[1]);
                 }
+            } else if (res && std::is_same<T, double>::value && s->use_i8 && ST == 5 && S.P == ds::i8::P && Nout == ds::i8::NOUT &&
+                       (Kloc == 256 || Kloc == 320) && Kh == Nout) {
+                // dense residual layer of the 5-slot-tile float64 cells: the per-electron contraction as an error-free split on the
+                // int8 matrix pipe (ds_i8.h); float64 in, float64 out, same shared term, same epilogue
+                uint8_t* wp = (uint8_t*)s->i8_wp;
+                double* sw = (double*)(wp + ds::i8::wp_bytes(64 * 5));
+                hipLaunchKernelGGL(ds::i8::k_i8_prep_w, dim3(ds::i8::NOUT / 16), dim3(256), 0, st, (const double*)blk(s->i_wloc[l]), Kloc, Nout, wp, sw);
+                const int ntiles = (int)(Bc * S.N);
+                const dim3 igrid((unsigned)std::min<int64_t>(Bc, s->n_cu));
+                if (Kloc == 320)
+                    hipLaunchKernelGGL((ds::i8::k_layer_i8<5, 2>), igrid, dim3(512), ds::i8::lds_bytes(), st, (const double*)c.G[gi], gts, (const uint4*)wp,
+                                       (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
+                else
+                    hipLaunchKernelGGL((ds::i8::k_layer_i8<4, 2>), igrid, dim3(512), ds::i8::lds_bytes(), st, (const double*)c.G[gi], gts, (const uint4*)wp,
+                                       (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
             } else if (res) {
                 ga.oe.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }
@@ -1417,6 +1437,16 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
             return fail("hipMalloc of the low-rank layer's weight table failed");
         }
     }
+    {
+        hipDeviceProp_t prop;
+        int devid = 0;
+        if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.multiProcessorCount > 0)
+            s->n_cu = prop.multiProcessorCount;
+        if (hipMalloc(&s->i8_wp, ds::i8::wp_bytes(64 * 5) + ds::i8::NOUT * sizeof(double)) != hipSuccess) {
+            ds_system_destroy(s);
+            return fail("hipMalloc of the int8 layer's weight planes failed");
+        }
+    }
     if (hipMalloc((void**)&s->clk_dev, 1024 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(s->clk_dev, 0, 1024 * sizeof(unsigned long long)) != hipSuccess) {
         ds_system_destroy(s);
@@ -1431,6 +1461,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     if (const char* e = getenv("DS_VAL_NB")) { const int v = atoi(e); s->val_nb = (v == 1 || v == 2 || v == 4) ? v : 0; }
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
+    s->use_i8 = getenv("DS_NO_I8") == nullptr;
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     s->use_wide = getenv("DS_NO_WIDE") == nullptr;
     s->wide_all = getenv("DS_WIDE_ALL") != nullptr;
@@ -1471,6 +1502,7 @@ void ds_system_destroy(ds_system* s) {
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->clk_dev) (void)hipFree(s->clk_dev);
     if (s->lr_w0t) (void)hipFree(s->lr_w0t);
+    if (s->i8_wp) (void)hipFree(s->i8_wp);
     if (s->blob64) (void)hipFree(s->blob64);
     if (s->blob32) (void)hipFree(s->blob32);
     delete s;
