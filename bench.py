@@ -29,6 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_I8_TOPS = 1024 * 2048 * 2.4e9 / 1e12      # v_mfma_i32_16x16x64_i8: 32768 operations per 16 cycles and SIMD
 PEAK_TFLOPS = {torch.float64: 78.6, torch.float32: 157.3}   # MI355X dense matrix = vector peak (datasheet)
 
 
@@ -65,6 +66,11 @@ def pmc_traffic(kernel_prefix, system, dtype_name, avg_launch_ms):
                                 read=e['read_bytes_per_launch'], write=e['write_bytes_per_launch'],
                                 walkers_per_launch=d.get('walkers_per_launch'), profile_avg_launch_ms=ref_ms,
                                 source=os.path.basename(f))
+                    # all kernels of one evaluation in the same profile (the driver runs several evaluations: k_features runs once in each)
+                    n_eval = max([v.get('launches', 0) for k, v in d['kernels'].items() if 'k_features<' in k] or [0])
+                    if n_eval:
+                        best['step_bytes'] = sum((v.get('read_bytes_per_launch', 0.0) + v.get('write_bytes_per_launch', 0.0)) * v.get('launches', 0)
+                                                 for k, v in d['kernels'].items() if 'k_calib_copy' not in k) / n_eval
         except Exception:
             pass
     return best
@@ -91,6 +97,48 @@ def cpu_model():
     except OSError:
         pass
     return 'unknown'
+
+
+def _cpu_worker(job):
+    """One of the concurrent processes of the all-cores CPU baseline: `reps` fori_loop iterations (hamiltonian.py:59-66) on the
+    vmapped sample with `threads` torch threads; -> seconds per iteration."""
+    cell, klist, net_kw, params_np, xs_np, threads, reps = job
+    import torch as _t
+    from torch.func import vmap
+    from oracle import hamiltonian as oham
+    from oracle import network as onet
+    _t.set_num_threads(threads)
+    net = onet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    p = onet.params_to_torch(params_np)
+    xs = _t.as_tensor(xs_np)
+    one_dir = vmap(lambda xx: oham.local_kinetic_energy_real_imag(net.apply, directions=1)(p, xx)[0])
+    one_dir(xs[:2])
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_dir(xs)
+    return (time.perf_counter() - t0) / reps
+
+
+def cpu_all_cores(cell, klist, net_kw, params_np, xs_np, t_dir_single, value_single, threads=16, max_procs=4):
+    """The same CPU restatement on MORE of the host: `n` processes x `threads` threads side by side, each on the whole sample
+    (torch's intra-op pool does not scale past ~16 threads on these small contractions, processes do).  The aggregate is
+    n x the single-process rate divided by the slow-down of an iteration under that load."""
+    n = max(1, min(max_procs, (os.cpu_count() or 1) // threads))
+    if n < 2:
+        return None
+    try:
+        import torch.multiprocessing as mp
+        reps = max(1, min(3, int(6.0 / max(t_dir_single, 1e-3))))
+        with mp.get_context('spawn').Pool(n) as pool:
+            ts = pool.map(_cpu_worker, [(cell, klist, net_kw, params_np, xs_np, threads, reps)] * n)
+        slow = max(ts) / t_dir_single
+        return dict(value=n * value_single / max(slow, 1.0), processes=n, threads_per_process=threads, cores=n * threads,
+                    slowdown_per_iteration=slow,
+                    sample=f'{n} processes x {threads} threads, each {reps} fori_loop iteration(s) on the same vmapped walkers at once: '
+                           f'{max(ts):.2f} s per iteration against {t_dir_single:.2f} s alone')
+    except Exception as e:                                  # the baseline is a courtesy number: never fail the bench line over it
+        log(f'all-cores cpu baseline skipped: {e!r}')
+        return None
 
 
 def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walkers=64):
@@ -146,8 +194,9 @@ def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walk
     for b in range(1, min(4, x_np.shape[0])):
         xb = torch.as_tensor(x_np[b])
         errs.append(abs(complex(e_gpu[b]) - (complex(ofl.stages(p, xb, klist, cell, net_kw)['ke']) + float(ew(xb)))))
+    allc = cpu_all_cores(cell, klist, net_kw, params_np, xs.numpy(), t_dir, nw / t_for, threads=cores)
     return dict(value=nw / t_for, unit='local-energy evals/s', cores=cores, kind='port', cpu=cpu_model(),
-                mode='for', hessian_mode_value=nh / t_h,
+                mode='for', hessian_mode_value=nh / t_h, all_cores=allc, host_threads=os.cpu_count(),
                 sample=f'{nw} walkers under torch.func.vmap; '
                        + (f'the complete fori_loop ({n3} iterations, hamiltonian.py:59-66) timed once: {t_loop:.1f} s, '
                           if n_it == n3 else f'{n_it} of the {n3} fori_loop iterations (hamiltonian.py:59-66) timed, scaled by {n3}/{n_it}, ')
@@ -364,11 +413,30 @@ def main():
     ms_hidden, n_launch = prof['single_hidden']
     flops_total = f_layer * args.batch * n_dense * args.steps            # this rank, timed region (dense hidden layers only)
     achieved = flops_total / (ms_hidden * 1e-3) / 1e12 if ms_hidden > 0 else 0.0
-    hidden_obj = {'bound': 'mfma', 'kernel': hidden_name + ' (dense hidden one-electron layer%s: K=%d MFMA GEMM + fused tanh-jet epilogue)' % ('s' if n_dense != 1 else '', h1 + nch * h2),
-                  'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None, 'traffic_detail': None,
-                  'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch, 'flops_per_walker_layer': f_layer,
-                  'timing': 'HIP events inside the library around every launch of this kernel over the timed region',
-                  'share_of_step': kms.get('single_hidden', 0.0) / max(sum(kms.values()), 1e-9)}
+    i8_layers = sysd.int8_layers()                                        # dense hidden layers per step that run as an int8 split (csrc/ds_i8.h)
+    if i8_layers and i8_layers == n_dense:
+        # the float64 contraction as 21 int8 digit-plane products per 64-row chunk on v_mfma_i32_16x16x64_i8: priced against THAT
+        # pipe (1024 SIMDs x 2048 operations per clock x 2.4 GHz; MI355X_MICROARCH.md lists >= 3944 measured), in the operations it
+        # executes; the float64 FLOPs it stands for are reported beside it
+        kloc = h1 + nch * h2
+        p_slots = (3 * n_e + 2 + 15) // 16 * 16
+        ops_layer = 21 * 2.0 * kloc * h1 * p_slots * n_e                  # int8 multiply-adds x 2 per walker and layer (executed, padded slots included)
+        ach8 = ops_layer * args.batch * n_dense * args.steps / (ms_hidden * 1e-3) / 1e12 if ms_hidden > 0 else 0.0
+        hidden_name = f'i8::k_layer_i8<{kloc // 64},2>'
+        hidden_obj = {'bound': 'mfma', 'kernel': hidden_name + ' (dense hidden one-electron layer%s: K=%d as an error-free int8 split, float64 in / out, fused tanh-jet epilogue)' % ('s' if n_dense != 1 else '', kloc),
+                      'mfma': 'i8-split s=6 (47-bit fixed point, 21 plane products, float64 recombination)',
+                      'achieved': ach8, 'peak': PEAK_I8_TOPS, 'unit': 'TOP/s', 'frac': ach8 / PEAK_I8_TOPS, 'traffic': None, 'traffic_detail': None,
+                      'f64_equivalent_tflops': achieved, 'f64_equivalent_frac_of_f64_peak': achieved / peak,
+                      'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch, 'flops_per_walker_layer': f_layer,
+                      'int8_ops_per_walker_layer': ops_layer,
+                      'timing': 'HIP events inside the library around every launch of this kernel over the timed region',
+                      'share_of_step': kms.get('single_hidden', 0.0) / max(sum(kms.values()), 1e-9)}
+    else:
+        hidden_obj = {'bound': 'mfma', 'kernel': hidden_name + ' (dense hidden one-electron layer%s: K=%d MFMA GEMM + fused tanh-jet epilogue)' % ('s' if n_dense != 1 else '', h1 + nch * h2),
+                      'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None, 'traffic_detail': None,
+                      'avg_launch_ms': ms_hidden / max(n_launch, 1), 'launches': n_launch, 'flops_per_walker_layer': f_layer,
+                      'timing': 'HIP events inside the library around every launch of this kernel over the timed region',
+                      'share_of_step': kms.get('single_hidden', 0.0) / max(sum(kms.values()), 1e-9)}
     if clk_ghz:
         # measured IN THIS RUN: one wave per workgroup of this kernel reads s_memtime (shader clock) and s_memrealtime (100 MHz)
         # at entry and exit; sum of cycles / sum of ticks over every workgroup of the timed region
@@ -399,7 +467,25 @@ def main():
                   'timing': 'HIP events, one extra profiled step outside the timed region',
                   'share_of_step': lr_ms / max(sum(kms.values()), 1e-9)}
     dominant = 'single_hidden' if kms.get('single_hidden', 0.0) >= orb_ms else 'orbital'
-    roofline = hidden_obj if dominant == 'single_hidden' else orbital_obj
+    roofline = dict(hidden_obj if dominant == 'single_hidden' else orbital_obj)
+    # the step as a whole: algorithmic float64 FLOPs of every matrix-core kernel of one step / the step's wall time / the float64
+    # MFMA peak (the kernel fractions above say how well each kernel uses its pipe, this one what the step delivers)
+    d_slots = 3 * n_e + 2
+    hd = net_kw['hidden_dims']
+    n_at = len(np.asarray(cell.original_cell.atom_coords()).reshape(-1, 3))
+    f_step = {'hidden_layers': f_layer * n_dense, 'lowrank_layer': (lr_obj or {}).get('flops_per_walker', 0.0), 'orbital_head': f_orb,
+              'shared_terms': sum(2.0 * nch * (hd[l - 1][0] if l else 4 * n_at) * hd[l][0] * d_slots for l in range(len(hd))),
+              'layer0': 0.0 if lowrank else 2.0 * n_e * (4 * n_at + nch * 4) * h1 * d_slots,
+              'pair_layers': sum(2.0 * n_e * n_e * 5 * (hd[l - 1][1] if l else 4) * hd[l][1] for l in range(len(hd) - 1)),
+              'det_traces': sum(2.0 * ndet * (2 * ns) * (2 * ns) * ns * d_slots for ns in cell.nelec if ns)}
+    if lowrank:
+        f_step['layer0'] = 2.0 * n_e * (4 * n_at + nch * 4) * h1 * d_slots
+    f_tot = sum(f_step.values())
+    step_ach = f_tot * args.batch / (dt / args.steps) / 1e12
+    roofline['step'] = {'achieved': step_ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': step_ach / peak, 'flops_per_walker': f_tot,
+                        'flops_per_walker_by_kernel': f_step,
+                        'note': 'algorithmic float64 FLOPs of all matrix-core kernels of a step / ms_per_step / float64 MFMA peak'}
+    roofline['step_traffic'] = None
     if mcmc:
         # Metropolis path: executed FLOPs of one log|psi| forward (value chain: the same contractions with one column per
         # walker: layers incl. the shared term, pair stream, orbital head) / its duration / peak
@@ -438,11 +524,12 @@ def main():
         out['other_scaling'] = other
     tr = pmc_traffic('ds::' + hidden_name.split(' ')[0].replace(',', ', '), args.system, args.dtype, hidden_obj['avg_launch_ms'])
     if tr:
-        hidden_obj['traffic'] = tr['bytes_per_launch']
+        roofline['traffic'] = hidden_obj['traffic'] = tr['bytes_per_launch']
+        roofline['step_traffic'] = tr.pop('step_bytes', None)        # counter bytes of every kernel of one step, same profile
         p_slots = (3 * n_e + 2 + 15) // 16 * 16
         # read every layer-input row once, write every output row once (weights and S are L2-resident)
         tr['algorithmic_bytes_per_launch'] = (8.0 if dtype == torch.float64 else 4.0) * tr['walkers_per_launch'] * n_e * p_slots * ((h1 + nch * h2) + h1)
-        hidden_obj['traffic_detail'] = tr
+        roofline['traffic_detail'] = hidden_obj['traffic_detail'] = tr
     if world == 1 and not args.no_cpu_baseline:
         params_np = {k: [{kk: vv.cpu().numpy() for kk, vv in d.items()} for d in v] for k, v in params.items()}
         cb, err = cpu_baseline(cell, klist, net_kw, params_np, x_np, aux.local_energy[:64].cpu().numpy(), args.cpu_seconds)

@@ -39,10 +39,13 @@ class ParamBlock(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/deepsolid_hip.h
 _VP = C.c_void_p
 SIGNATURES = {
+    'ds_device_widths': (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'ds_system_create': (C.c_int, [C.POINTER(SystemDesc), C.POINTER(_VP)]),
     'ds_system_destroy': (None, [_VP]),
     'ds_last_error': (C.c_char_p, []),
     'ds_param_count': (C.c_int64, [_VP]),
+    'ds_int8_layers': (C.c_int, [_VP]),
     'ds_param_layout': (C.c_int, [_VP, C.POINTER(ParamBlock), C.c_int]),
     'ds_workspace_bytes': (C.c_int64, [_VP, C.c_int64]),
     'ds_logpsi': (C.c_int, [_VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, C.c_int64, _VP]),

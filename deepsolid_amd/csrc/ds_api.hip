@@ -93,14 +93,12 @@ struct ds_system {
     // block indices
     std::vector<int> i_wloc, i_wsh, i_b, i_w2, i_b2, i_worb, i_wsh_orb, i_borb, i_pi, i_sg;
     bool use_last = false;
-    // optional two-way chunk pipelining (DS_STREAMS=2): bandwidth-bound kernels of one chunk overlap the MFMA-bound
-    // kernels of the other; the side streams fork from / join the caller's stream with events
-    int n_streams = 1;
+    // the reference's widths (network.py:111-132) as given to ds_system_create; `d` holds the widths the kernels run (zero-padded:
+    // plan_widths) and res1 / res2 say where the reference adds a residual (network.py:525-528: in == out of the REFERENCE widths)
+    int32_t ref_single[DS_MAX_LAYERS] = {0}, ref_double[DS_MAX_LAYERS] = {0};
+    bool res1[DS_MAX_LAYERS] = {false}, res2[DS_MAX_LAYERS] = {false};
     bool no_lu_wave = false;          // DS_NO_LU_WAVE: log det of 16 < n <= 64 by the Gauss-Jordan inverse kernel (as before round 3)
     int val_nb = 0;                   // DS_VAL_NB = 1 / 2 / 4: one wave-tile width for the value chain's GEMMs (default: by workgroup count)
-    bool no_fuse_means = false;       // DS_NO_FUSE_MEANS: the value chain re-reads H2 for the partner means (k_m2_expand_val)
-    bool det_half_slots = false;      // DS_DET_HALF_SLOTS: the older half-slot-tile mode of the determinant-trace kernel
-    bool det_blocked = false;         // DS_DET_BLOCKED: k_det_trace_blocked for every n > 16 (A/B against the compile-time-size kernels)
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
@@ -111,8 +109,6 @@ struct ds_system {
     bool use_wide = true;             // DS_NO_WIDE unset: the chunked kernels of ds_wide.h for more than 10 slot tiles where they are faster
     bool wide_all = false;            // DS_WIDE_ALL: ... everywhere (tests, A/B runs)
     int dbg = 0;                      // DS_DBG (kernel development): 32 = phase stamps of one wave; 1 / 2 switch arithmetic off in a `make EXP=1` build only
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // optional per-kernel timing with HIP events on the caller's stream (ds_profile_*)
     bool prof_on = false;
     int prof_only = -1;               // >= 0: record events for this kernel kind only (keeps the timed region undisturbed)
@@ -389,9 +385,7 @@ inline void val_geom(int Nout, int NB, dim3* block, unsigned* gz) {
 inline int m2_rc(int K2) { return K2 % 16 == 0 ? 16 : K2; }
 
 // k_m2_expand: feature splits (grid.z) so that a workgroup's pair jets take at most ~8 KB of LDS
-static int g_m2_split_override = 0;      // DS_M2_SPLIT (kernel development)
 template <typename T> inline unsigned m2_split(int K2, int N) {
-    if (g_m2_split_override > 0 && K2 % g_m2_split_override == 0) return (unsigned)g_m2_split_override;
     unsigned z = 1;
     while (z < 8 && K2 % (2 * z) == 0 && (size_t)(K2 / z) * 5 * N * sizeof(T) > 8192) z *= 2;
     return z;
@@ -408,6 +402,24 @@ int copy_out(DumpReq<T>* dr, const T* src, size_t n, hipStream_t st) {
     HIP_OK(hipMemcpyAsync(dr->out, src, m * sizeof(T), hipMemcpyDeviceToDevice, st));
     dr->written = (int64_t)m;
     return 0;
+}
+
+// Static part of two dispatch decisions of the chain (the dims of sd and sf are the same):
+// the first hidden layer on the low-rank form of the layer-0 output (k_layer1_lr; off for stage dumps) ...
+inline bool lowrank_possible(const ds_system* s, int ST) {
+    const ds::SysDev<double>& S = s->sd;
+    const int K0loc = S.h1[0] + S.nch * S.h2[0], K0sh = S.nch * S.h1[0];
+    const int lr_nc = std::max(2, (K0loc + K0sh + 4 + 15) / 16);      // column tiles of the per-electron weights C (instances: 2, 3, 4)
+    // (worth it when the weights C cost fewer products than the rows they replace: Kh / 4 k-steps of NB x NC tiles against
+    //  (Kh - K0 - 4) / 4 k-steps of NB x ST -- not for the one- or two-tile cells, N <= 10)
+    return s->use_lr && S.n_layers >= 2 && !s->res1[0] && lr_nc <= 4 && S.h1[1] % 16 == 0 && (S.nch * S.h2[1]) % 4 == 0 &&
+           3 * (K0loc + K0sh + 4) <= S.h1[1] && lr_nc * S.h1[1] < (S.h1[1] - K0loc - K0sh - 4) * ST;
+}
+// ... and a dense residual hidden layer l with its per-electron contraction as an int8 split (ds_i8.h: float64, 5 slot tiles, 256 features)
+inline bool int8_layer(const ds_system* s, int l) {
+    const ds::SysDev<double>& S = s->sd;
+    const int Kloc = S.h1[l] + S.nch * S.h2[l];
+    return s->dtype == 0 && s->use_i8 && l >= 1 && s->res1[l] && S.P == ds::i8::P && S.h1[l + 1] == ds::i8::NOUT && (Kloc == 256 || Kloc == 320);
 }
 
 // The forward-Laplacian chain on a chunk of Bc walkers.
@@ -432,8 +444,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     const int lr_nc = std::max(2, (K0loc + K0sh + 4 + 15) / 16);      // column tiles of the per-electron weights C (instances: 2, 3, 4)
     // (worth it when the weights C cost fewer products than the rows they replace: Kh / 4 k-steps of NB x NC tiles against
     //  (Kh - K0 - 4) / 4 k-steps of NB x ST -- not for the one- or two-tile cells, N <= 10)
-    const bool lr_on = s->use_lr && !dr && S.n_layers >= 2 && lr_nc <= 4 && S.h1[1] % 16 == 0 && (S.nch * S.h2[1]) % 4 == 0 &&
-                       3 * (K0loc + K0sh + 4) <= S.h1[1] && lr_nc * S.h1[1] < (S.h1[1] - K0loc - K0sh - 4) * ST;
+    const bool lr_on = !dr && lowrank_possible(s, ST);
     // 1. features
     {
         ProfScope ps(s, DS_PROF_FEATURES, st);
@@ -467,7 +478,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
             if (K2 % 4) return fail("pair-stream width %d is not a multiple of 4", K2);
             dim3 grid((S.NP / 16 + 3) / 4, (unsigned)Bc);
-            const bool res = K2 == K2o;
+            const bool res = s->res2[l];
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
             ProfScope ps(s, DS_PROF_TWO_LAYER, st);
 #define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, false>), grid, dim3(256), 0, st, S, c.H2[hi], K2, W2, b2, c.H2[hi ^ 1])
@@ -478,7 +489,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         // one-electron stream layer: GEMM over the N electron tiles + the shared spin-mean tile, then epilogue
         const int hin = hi;                                // the layer reads the pair stream of its own level (hi flips below)
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
-        const bool res = Kh == Nout;
+        const bool res = s->res1[l];
         if (res && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         {
             dim3 block; unsigned gz;
@@ -539,8 +550,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                     hipLaunchKernelGGL((ds::k_layer0_means<T, STC>), dim3(S.nch * nfb * nck, (unsigned)Bc), dim3(256), 0, st, S, c.XL,
                                        (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, blk(s->i_wloc[0]), K0loc, c.ZB, Nout, S.P, c.YO, c.MEAN[1]);
                 }
-            } else if (res && std::is_same<T, double>::value && s->use_i8 && ST == 5 && S.P == ds::i8::P && Nout == ds::i8::NOUT &&
-                       (Kloc == 256 || Kloc == 320) && Kh == Nout) {
+            } else if (int8_layer(s, l)) {
                 // dense residual layer of the 5-slot-tile float64 cells: the per-electron contraction as an error-free split on the
                 // int8 matrix pipe (ds_i8.h); float64 in, float64 out, same shared term, same epilogue
                 uint8_t* wp = (uint8_t*)s->i8_wp;
@@ -641,14 +651,14 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const size_t ybytes8 = (size_t)n * 2 * n * 8 * sizeof(T) + 512 * sizeof(ds::Cx<T>);
         const bool sw8 = ybytes16 > 160 * 1024;
         const size_t ybytes = sw8 ? ybytes8 : ybytes16;
-        if ((2 * n) % 4 == 0 && ybytes <= 160 * 1024 && nt <= 6 && !s->det_valu && !(s->det_blocked && n > 16)) {
+        if ((2 * n) % 4 == 0 && ybytes <= 160 * 1024 && nt <= 6 && !s->det_valu) {
 #define DS_TRMF(NTV, SWV, NWV, NF) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV, NF>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp], (s->dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr)
 #define DS_TRM(NTV, SWV, NWV) hipLaunchKernelGGL((ds::k_det_trace_mfma<T, NTV, SWV, NWV>), dim3(S.K, (unsigned)Bc), dim3(64 * NWV), ybytes, st, S, c.MOUT, L.MOUT,  \
                                             L.mout_off[sp], sp, c.MINV, L.MINV, L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS,     \
                                             L.dets_off[sp])
-            if (sw8 && (n == 32 || n == 48) && !s->det_half_slots) {
+            if (sw8 && (n == 32 || n == 48)) {
                 // row-split mode: half the rows of a full slot tile in LDS, nothing computed twice
                 // (4 waves: the A fragments + three operand sets need the 512-register budget; 8 waves with one set less
                 //  measured slower, 71.3 vs 68.7 ms per diamond step)
@@ -747,7 +757,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
     hipLaunchKernelGGL((ds::k_features_val<T, 1>), dim3((unsigned)ng, fsplit), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
                        blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), vb.Gl[0], vb.MEAN0, vb.H2l[0], Q);
     const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
-    const bool fuse_means = S.n_up >= 8 && (S.n_dn >= 8 || S.n_dn == 0) && !s->no_fuse_means;
+    const bool fuse_means = S.n_up >= 8 && (S.n_dn >= 8 || S.n_dn == 0);
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
         T* Gin = vb.Gl[l]; T* Gout = vb.Gl[l + 1];
@@ -763,7 +773,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
             const int K2o = S.h2[l + 1];
             if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
             dim3 grid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
-            const bool res = K2 == K2o;
+            const bool res = s->res2[l];
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
             // the last pair layer's output is only needed as means unless the activations are kept (gradient pass) or the
             // orbital head / a later layer reads H2 again without a pair layer in between
@@ -776,7 +786,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         }
         if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
-        if (Kh == Nout && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
+        if (s->res1[l] && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         dim3 block; unsigned gz;
         gemm_geom(Nout, 4, &block, &gz);
         // (a float32 MFMA lasts half as long: the same rule on half the count -- diamond, 1024 walkers: forward 3.46 -> 3.40 ms)
@@ -806,7 +816,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
 #define DS_VHID(NBV) { dim3 hb; unsigned hz; val_geom(Nout, NBV, &hb, &hz); \
             hipLaunchKernelGGL((ds::k_jet_gemm<T, NBV, 5, 4>), dim3(S.N, (unsigned)ng, hz), hb, (ds::gemm_stash_bytes<T, NBV, 5>(hb.x)), st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc, \
                                (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, gws, gts, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{}); }
-        if (Kh == Nout) {
+        if (s->res1[l]) {
             if (nbh == 4) DS_VHID(4) else if (nbh == 2) DS_VHID(2) else DS_VHID(1)
         } else
 #undef DS_VHID
@@ -941,26 +951,6 @@ int local_energy_impl(ds_system* s, const void* params, const void* x, int64_t B
     int64_t chunk = ws_bytes / (int64_t)(s->ws.per_walker * sizeof(T));
     if (chunk < 1) return fail("workspace too small: %lld bytes < %zu per walker", (long long)ws_bytes, s->ws.per_walker * sizeof(T));
     chunk = std::min<int64_t>(chunk, 65535);      // grid.y carries the walker index
-    if (s->n_streams == 2 && chunk >= 2 && B > chunk / 2) {
-        // two half-size workspaces, chunks alternate between two side streams
-        const int64_t half = chunk / 2;
-        const size_t half_bytes = ((size_t)half * s->ws.per_walker * sizeof(T) + 255) / 256 * 256;
-        if (half_bytes + (size_t)half * s->ws.per_walker * sizeof(T) > (size_t)ws_bytes) return fail("workspace too small for DS_STREAMS=2");
-        char* wsp[2] = {(char*)ws, (char*)ws + half_bytes};
-        HIP_OK(hipEventRecord(s->ev_fork, st));
-        for (int k = 0; k < 2; ++k) HIP_OK(hipStreamWaitEvent(s->side[k], s->ev_fork, 0));
-        int k = 0;
-        for (int64_t b0 = 0; b0 < B; b0 += half, k ^= 1) {
-            const int64_t Bc = std::min(half, B - b0);
-            int rc = run_chain<T>(s, (const T*)params, (const T*)x + b0 * 3 * S.N, Bc, wsp[k], s->side[k], out_ke ? (T*)out_ke + 2 * b0 : nullptr,
-                                  out_logabs ? (T*)out_logabs + b0 : nullptr, out_phase ? (T*)out_phase + 2 * b0 : nullptr, nullptr);
-            if (rc) return rc;
-        }
-        for (int j = 0; j < 2; ++j) {
-            HIP_OK(hipEventRecord(s->ev_join[j], s->side[j]));
-            HIP_OK(hipStreamWaitEvent(st, s->ev_join[j], 0));
-        }
-    } else
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t Bc = std::min(chunk, B - b0);
         const T* xb = (const T*)x + b0 * 3 * S.N;
@@ -1184,7 +1174,7 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
                                gp.korb_pad, Kl, S.h2[L], H2BAR[h2i]);
         for (int l = L - 1; l >= 0; --l) {
             const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1], Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
-            const bool res = Kh == Nout;
+            const bool res = s->res1[l];
             T* HBc = HB[hbi];
             if (res)
                 hipLaunchKernelGGL((ds::k_layer_bwd_prep<T, true>), dim3(Nout / 4, (unsigned)ng), dim3(4 * PV), 0, st, S, D1, ld1, MB, MB2, CARRY,
@@ -1220,19 +1210,18 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
                                        GBAR, Kpad, Kh, K2, H2BAR[h2i]);
             } else {
                 const int K2o = S.h2[l + 1];
-                const bool res2 = K2 == K2o, dx = l > 0;
+                const bool res2 = s->res2[l], dx = l > 0;
                 const T* W2 = blk(s->i_w2[l]);
                 T* HBn = H2BAR[h2i]; T* HBi = H2BAR[h2i ^ 1];
 #define DS_TWOB(NTI, NTO, RES, DX) hipLaunchKernelGGL((ds::k_two_bwd<T, NTI, NTO, RES, DX>), pgrid, dim3(256), 0, st, S, HBn, vb.H2l[l + 1], \
                                                       vb.H2l[l], W2, GBAR, Kpad, Kh, Z2BAR, HBi)
                 if (!dx) { if (K2o == 32) DS_TWOB(1, 2, false, false); else DS_TWOB(1, 1, false, false); }
-                else if (K2 == 32 && K2o == 32) DS_TWOB(2, 2, true, true);
-                else if (K2 == 16 && K2o == 16) DS_TWOB(1, 1, true, true);
+                else if (K2 == 32 && K2o == 32) { if (res2) DS_TWOB(2, 2, true, true); else DS_TWOB(2, 2, false, true); }
+                else if (K2 == 16 && K2o == 16) { if (res2) DS_TWOB(1, 1, true, true); else DS_TWOB(1, 1, false, true); }
                 else if (K2 == 32 && K2o == 16) DS_TWOB(2, 1, false, true);
                 else if (K2 == 16 && K2o == 32) DS_TWOB(1, 2, false, true);
                 else return fail("parameter gradient: unsupported pair-stream widths %d -> %d", K2, K2o);
 #undef DS_TWOB
-                (void)res2;
                 const int J = 5 * S.NP;
                 outer(vb.H2l[l], (size_t)(PV / 5) * K2 * J, (size_t)K2 * J, J, Z2BAR, (size_t)(PV / 5) * K2o * J, (size_t)K2o * J, J, PV / 5,
                       J, K2, K2o, boff(s->i_w2[l]), PV / 5);
@@ -1368,6 +1357,33 @@ int mcmc_asymmetric_impl(ds_system* s, const void* params, void* x_, void* lp_, 
 }
 
 
+// Reference widths -> the widths the kernels run and the residual pattern.  The one-electron kernels run multiples of 64 features,
+// the pair kernels 16 or 32; any other width runs with ZERO-PADDED weights and biases, which is exact: a padded feature is
+// tanh(0) = 0 in every layer, has zero jets, adds nothing to the spin means and meets zero rows in the next layer.  A residual
+// is added exactly where the reference adds one (network.py:525-528: input width == output width, of the reference's widths),
+// whatever the padded widths are.  n_in_single / n_in_double: widths of the input features (nf x atoms, nf; nf = 4 'nu', 7 'tri').
+int plan_widths(const int32_t* hs, const int32_t* hd, int n_layers, int n_in_single, int n_in_double, int n_double, int32_t* ps,
+                int32_t* pd, int32_t* rs, int32_t* rd) {
+    if (n_layers < 1 || n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
+    for (int l = 0; l < n_layers; ++l) {
+        const int a = hs[l], b = hd[l];
+        if (a < 1 || a > 1024) return fail("hidden_single: one-electron widths are supported in 1..1024 (layer %d: %d)", l, a);
+        if (l < n_double && (b < 1 || b > 32)) return fail("hidden_double: pair-stream widths are supported in 1..32 (layer %d: %d)", l, b);
+        ps[l] = rup(a, 64);
+        pd[l] = (b >= 1 && b <= 16) ? 16 : 32;            // (beyond n_double the width is unused: network.py:118-121)
+        rs[l] = a == (l == 0 ? n_in_single : hs[l - 1]);
+        rd[l] = l < n_double && b == (l == 0 ? n_in_double : hd[l - 1]);
+    }
+    if (rs[0] && n_in_single % 64)
+        return fail("hidden_single[0] = %d equals the width of the input features: the reference adds a residual there (network.py:525), "
+                    "which the kernels run only for input widths that are multiples of 64", hs[0]);
+    if (rd[0])
+        return fail("hidden_double[0] = %d equals the width of the pair features: the reference adds a residual there (network.py:527), "
+                    "which the pair kernels do not run", hd[0]);
+    return 0;
+}
+
+// d: the descriptor with the DEVICE widths (plan_widths)
 int check_arch(const ds_system_desc* d) {
     if (d->dtype != 0 && d->dtype != 1) return fail("dtype must be 0 (f64) or 1 (f32)");
     if (d->distance_type != 0 && d->distance_type != 1) return fail("Unrecognized distance function.");
@@ -1382,14 +1398,14 @@ int check_arch(const ds_system_desc* d) {
     const int N = d->n_up + d->n_dn, tiles = (3 * N + 2 + 15) / 16, nmat = d->full_det ? N : std::max(d->n_up, d->n_dn);
     if (nmat > 64) return fail("determinant matrices larger than 64 x 64 are not supported (n = %d): the trace kernels keep a matrix row per lane group", nmat);
     if (tiles < 1 || tiles > ds::DS_MAX_TILES)
-        return fail("no kernel instance for %d jet-slot tiles (N = %d electrons): supported are N <= 132", tiles, N);
+        return fail("no kernel instance for %d jet-slot tiles (N = %d electrons): supported are N <= 128 (64 with full_det)", tiles, N);
     const int n_double = d->use_last_layer ? d->n_layers : d->n_layers - 1;
     const int nch = d->n_dn > 0 ? 2 : 1;
     for (int l = 0; l < d->n_layers; ++l) {
         if (d->hidden_single[l] % 64 || d->hidden_single[l] < 64 || d->hidden_single[l] > 1024)
-            return fail("hidden_single must be a multiple of 64 in 64..1024 (layer %d: %d)", l, d->hidden_single[l]);
+            return fail("internal: device width %d of layer %d is not a multiple of 64 in 64..1024", d->hidden_single[l], l);
         if (l < n_double && d->hidden_double[l] != 16 && d->hidden_double[l] != 32)
-            return fail("hidden_double must be 16 or 32 (layer %d: %d)", l, d->hidden_double[l]);
+            return fail("internal: device pair width %d of layer %d is not 16 or 32", d->hidden_double[l], l);
     }
     const int k_orb = d->hidden_single[d->n_layers - 1] + (d->use_last_layer ? nch * d->hidden_double[d->n_layers - 1] : 0);
     if (k_orb % 16) return fail("orbital head with K = %d input rows: the GEMM's operand ring needs K %% 16 == 0", k_orb);
@@ -1403,14 +1419,39 @@ extern "C" {
 
 const char* ds_last_error(void) { return g_err.c_str(); }
 
-int ds_system_create(const ds_system_desc* desc, ds_system** out) {
-    if (!desc || !out) return fail("null argument");
+int ds_device_widths(const int32_t* hidden_single, const int32_t* hidden_double, int32_t n_layers, int32_t n_in_single, int32_t n_in_double,
+                     int32_t n_double, int32_t* dev_single, int32_t* dev_double, int32_t* res_single, int32_t* res_double) {
+    if (!hidden_single || !hidden_double || !dev_single || !dev_double || !res_single || !res_double) return fail("null argument");
+    return plan_widths(hidden_single, hidden_double, n_layers, n_in_single, n_in_double, n_double, dev_single, dev_double, res_single, res_double);
+}
+
+int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
+    if (!ref_desc || !out) return fail("null argument");
+    // the descriptor carries the REFERENCE's hidden_dims; from here on `desc` has the widths the kernels run
+    ds_system_desc dev_desc = *ref_desc;
+    int32_t rs[DS_MAX_LAYERS] = {0}, rd[DS_MAX_LAYERS] = {0};
+    {
+        if (ref_desc->distance_type != 0 && ref_desc->distance_type != 1) return fail("Unrecognized distance function.");
+        if (ref_desc->n_layers < 1 || ref_desc->n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
+        const int nf = ref_desc->distance_type == 0 ? 4 : 7;
+        const int n_double = ref_desc->use_last_layer ? ref_desc->n_layers : ref_desc->n_layers - 1;
+        if (int rc = plan_widths(ref_desc->hidden_single, ref_desc->hidden_double, ref_desc->n_layers, nf * ref_desc->n_atoms_prim, nf, n_double,
+                                 dev_desc.hidden_single, dev_desc.hidden_double, rs, rd))
+            return rc;
+    }
+    const ds_system_desc* desc = &dev_desc;
     if (int rc = check_arch(desc)) return rc;
     if (!desc->prim_atoms || !desc->klist_up || (desc->n_dn > 0 && !desc->klist_dn) || !desc->sim_atoms || !desc->sim_charges ||
         (desc->n_g > 0 && (!desc->gpoints || !desc->gweight || !desc->ion_exp_re || !desc->ion_exp_im)))
         return fail("null array pointer in ds_system_desc");
     ds_system* s = new ds_system();
     s->d = *desc;
+    for (int l = 0; l < desc->n_layers; ++l) {
+        s->ref_single[l] = ref_desc->hidden_single[l];
+        s->ref_double[l] = ref_desc->hidden_double[l];
+        s->res1[l] = rs[l] != 0;
+        s->res2[l] = rd[l] != 0;
+    }
     s->dtype = desc->dtype;
     s->use_last = desc->use_last_layer != 0;
     std::vector<double> h64;
@@ -1453,11 +1494,7 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
         return fail("hipMalloc of the clock-probe counters failed");
     }
     // environment switches are read here, once; the launch paths never call getenv
-    if (const char* e = getenv("DS_STREAMS")) s->n_streams = atoi(e) == 2 ? 2 : 1;
     s->det_valu = getenv("DS_DET_VALU") != nullptr;
-    s->det_blocked = getenv("DS_DET_BLOCKED") != nullptr;
-    s->det_half_slots = getenv("DS_DET_HALF_SLOTS") != nullptr;
-    s->no_fuse_means = getenv("DS_NO_FUSE_MEANS") != nullptr;
     if (const char* e = getenv("DS_VAL_NB")) { const int v = atoi(e); s->val_nb = (v == 1 || v == 2 || v == 4) ? v : 0; }
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
@@ -1465,41 +1502,14 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out) {
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     s->use_wide = getenv("DS_NO_WIDE") == nullptr;
     s->wide_all = getenv("DS_WIDE_ALL") != nullptr;
-    if (const char* e = getenv("DS_M2_SPLIT")) g_m2_split_override = atoi(e);
     // (grid.y carries the walker index: at most 65535 walkers per launch)
     if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::min<int64_t>(65535, std::max<int64_t>(1, atol(e)));
-    if (s->n_streams == 2) {
-        bool ok = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) == hipSuccess;
-        // DS_CUMASK=1: each side stream owns one half of the CU mask bits (experiment: chunks at different phases on disjoint CUs)
-        const char* cm = getenv("DS_CUMASK");
-        for (int k = 0; k < 2 && ok; ++k) {
-            if (cm && atoi(cm) > 0) {
-                uint32_t mask[8];
-                const int mode = atoi(cm);
-                for (int i = 0; i < 8; ++i)
-                    mask[i] = mode == 1 ? ((i < 4) == (k == 0) ? 0xffffffffu : 0u)            // lower / upper 128 bits
-                                        : (k == 0 ? 0x55555555u : 0xaaaaaaaau);                // even / odd bits
-                ok = hipExtStreamCreateWithCUMask(&s->side[k], 8, mask) == hipSuccess;
-            } else
-                ok = hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&s->ev_join[k], hipEventDisableTiming) == hipSuccess;
-        }
-        if (!ok) {
-            ds_system_destroy(s);
-            return fail("DS_STREAMS=2: creating the side streams / events failed");
-        }
-    }
     *out = s;
     return 0;
 }
 
 void ds_system_destroy(ds_system* s) {
     if (!s) return;
-    for (int k = 0; k < 2; ++k) {
-        if (s->side[k]) (void)hipStreamDestroy(s->side[k]);
-        if (s->ev_join[k]) (void)hipEventDestroy(s->ev_join[k]);
-    }
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->clk_dev) (void)hipFree(s->clk_dev);
     if (s->lr_w0t) (void)hipFree(s->lr_w0t);
     if (s->i8_wp) (void)hipFree(s->i8_wp);
@@ -1509,6 +1519,15 @@ void ds_system_destroy(ds_system* s) {
 }
 
 int64_t ds_param_count(const ds_system* s) { return s ? s->nparams : -1; }
+
+int ds_int8_layers(const ds_system* s) {
+    if (!s) return -1;
+    const ds::TileOps<double>* to = ds::tile_ops<double>(s->sd.P / 16);
+    const bool lr = to && lowrank_possible(s, to->ST);
+    int n = 0;
+    for (int l = 1; l < s->sd.n_layers; ++l) n += (int8_layer(s, l) && !(lr && l == 1)) ? 1 : 0;
+    return n;
+}
 
 int ds_param_layout(const ds_system* s, ds_param_block* blocks, int max_blocks) {
     if (!s) return -1;

@@ -13,8 +13,8 @@
 
 // Timing experiments that switch parts of the arithmetic OFF (tools/exp_dbg.sh) exist only in a library
 // built with `make EXP=1`: in the shipped build the DS_DBG bits that would change a result are compiled out, so no
-// environment variable can make the product path return wrong energies.  (The clock probe and the phase stamps never
-// change a result and stay.)
+// environment variable can make the product path return wrong energies.  (The clock probe and the phase stamps of the hidden-layer
+// kernel never change a result; since round 5 they are compiled into the same builds only.)
 #ifdef DS_TIMING_EXPERIMENTS
 #define DS_EXP(x) (x)
 #else

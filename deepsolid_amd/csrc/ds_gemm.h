@@ -289,9 +289,10 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     }
     const int lr = lane & 15, lq = lane >> 4, n0 = (zb * (blockDim.x >> 6) + wave) * 16 * NB;
     if (n0 >= Nout) return;                      // column blocks beyond Nout (grid.z rounds up)
+    // (the clock probe and the phase stamps exist in `make EXP=1` builds only: the shipped kernel carries no instrumentation)
     long long clk_c0 = 0, clk_r0 = 0;
-    if (EPI == 2 && oe.clk && wave == 0) { clk_c0 = clock64(); clk_r0 = wall_clock64(); }
-    unsigned long long* tl = (EPI == 2 && oe.clk && (oe.dbg & 32) && blockIdx.x == gridDim.x / 8 && blockIdx.y == gridDim.y / 2 && wave == 0 && lane == 0) ? oe.clk + 2 : nullptr;
+    if (EPI == 2 && DS_EXP(oe.clk != nullptr) && wave == 0) { clk_c0 = clock64(); clk_r0 = wall_clock64(); }
+    unsigned long long* tl = (EPI == 2 && DS_EXP(oe.clk != nullptr) && (oe.dbg & 32) && blockIdx.x == gridDim.x / 8 && blockIdx.y == gridDim.y / 2 && wave == 0 && lane == 0) ? oe.clk + 2 : nullptr;
     int n_tl = 0;
     auto stamp = [&]() { if (EPI == 2 && tl) { __builtin_amdgcn_s_waitcnt(0); tl[n_tl++] = (unsigned long long)clock64(); } };
     stamp();
@@ -537,7 +538,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         else layer_epilogue<T, NB, ST, EPI, NA>(acc, Gi, Go, stash, n0, lane, P);
     }
     stamp();
-    if (EPI == 2 && oe.clk && wave == 0 && lane == 0) {
+    if (EPI == 2 && DS_EXP(oe.clk != nullptr) && wave == 0 && lane == 0) {
         atomicAdd(oe.clk, (unsigned long long)(clock64() - clk_c0));
         atomicAdd(oe.clk + 1, (unsigned long long)(wall_clock64() - clk_r0));
     }

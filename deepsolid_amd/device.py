@@ -34,45 +34,33 @@ def _require_gpu():
                            'oracle/ and is test infrastructure only)')
 
 
-def device_widths(hidden_dims, n_in_ref, n_double=None):
-    """The widths the kernels run for the reference's `hidden_dims` (network.py:111-132).
+def device_plan(hidden_dims, n_in_single, n_in_double=4, n_double=None):
+    """-> (device widths, residual flags) for the reference's `hidden_dims` (network.py:111-132), from the library itself
+    (`ds_device_widths`: host code of the C ABI, no GPU needed; `ds_system_create` applies the same plan to its descriptor).
 
-    The kernels need one-electron widths in multiples of 64 and pair widths of 16 or 32; any other width is run with ZERO-PADDED
+    The kernels run one-electron widths in multiples of 64 and pair widths of 16 or 32; any other width runs with ZERO-PADDED
     weights and biases, which is exact: a padded feature is tanh(0) = 0 in every layer, has zero jets, adds nothing to the spin
-    means and meets zero rows in the next layer.  The residual connections follow the reference's widths (network.py:525-528:
-    in == out), and the library decides them from the widths it is given, so the padded widths of consecutive layers are made
-    equal exactly where the reference's are (one more block of padding where two different widths would pad to the same one).
-    `n_in_ref`: width of the one-electron input features (the library pads it to the MFMA k-step, a multiple of 4);
-    `n_double`: number of pair layers that run (network.py:118-121: the last width is unused without `use_last_layer`)."""
-    n_double = len(hidden_dims) if n_double is None else n_double
-    h1, h2 = [], []
-    n_in_single = (int(n_in_ref) + 3) // 4 * 4
-    for l, (a, b) in enumerate(hidden_dims):
-        a, b = int(a), int(b)
-        if a < 1 or b < 1:
-            raise ValueError(f'hidden_dims[{l}] = {(a, b)}')
-        if b > 32:
-            raise ValueError(f'hidden_dims[{l}][1] = {b}: pair-stream widths beyond 32 have no kernel instance')
-        pa, pb = (a + 63) // 64 * 64, (16 if b <= 16 else 32)
-        if l == 0:
-            if pa == n_in_single and a != int(n_in_ref):
-                pa += 64
-        else:
-            ra, rb = int(hidden_dims[l - 1][0]), int(hidden_dims[l - 1][1])
-            if a == ra:
-                pa = h1[-1]
-            elif pa == h1[-1]:
-                pa += 64
-            if b == rb:
-                pb = h2[-1]
-            elif pb == h2[-1] and l < n_double:
-                if pb == 32:
-                    raise ValueError(f'hidden_dims[{l - 1}][1] = {rb} and hidden_dims[{l}][1] = {b} differ and both need the 32-wide '
-                                     'pair kernels: no padded width keeps them apart')
-                pb = 32
-        h1.append(pa)
-        h2.append(pb)
-    return tuple(zip(h1, h2))
+    means and meets zero rows in the next layer.  A residual is added exactly where the reference adds one (network.py:525-528:
+    in == out of the REFERENCE's widths) -- an explicit flag per layer and stream, independent of the padded widths.
+    `n_in_single` / `n_in_double`: widths of the input features (nf x atoms, nf); `n_double`: number of pair layers that run
+    (network.py:118-121: the last width is unused without `use_last_layer`).  Raises ValueError for what the kernels cannot run:
+    widths beyond 1024 / 32, and a first layer as wide as its input features (the reference's residual there needs an input
+    width that is a multiple of 64; the pair stream has none)."""
+    import ctypes as C
+    lib = _lib.load()
+    n = len(hidden_dims)
+    n_double = n if n_double is None else n_double
+    arr = C.c_int32 * max(n, 1)
+    hs, hd = arr(*[int(h[0]) for h in hidden_dims]), arr(*[int(h[1]) for h in hidden_dims])
+    ps, pd, rs, rd = arr(), arr(), arr(), arr()
+    if lib.ds_device_widths(hs, hd, n, int(n_in_single), int(n_in_double), int(n_double), ps, pd, rs, rd) != 0:
+        raise ValueError(lib.ds_last_error().decode())
+    return tuple(zip(ps[:n], pd[:n])), tuple(zip((bool(v) for v in rs[:n]), (bool(v) for v in rd[:n])))
+
+
+def device_widths(hidden_dims, n_in_single, n_double=None, n_in_double=4):
+    """The widths the kernels run for the reference's `hidden_dims` (see `device_plan`)."""
+    return device_plan(hidden_dims, n_in_single, n_in_double, n_double)[0]
 
 
 class DeviceSystem:
@@ -89,9 +77,12 @@ class DeviceSystem:
         self.n = sum(self.nelec)
         self.n_det = int(net_kw['determinants'])
         self.hidden_dims = tuple(tuple(int(v) for v in h) for h in net_kw['hidden_dims'])
-        nf_in = (4 if net_kw.get('distance_type', 'nu') == 'nu' else 7) * np.asarray(prim.atom_coords()).reshape(-1, 3).shape[0]
-        self.device_dims = device_widths(self.hidden_dims, nf_in,      # what the kernels run (zero-padded weights)
-                                         len(self.hidden_dims) - (0 if net_kw.get('use_last_layer', False) else 1))
+        nf = 4 if net_kw.get('distance_type', 'nu') == 'nu' else 7
+        nf_in = nf * np.asarray(prim.atom_coords()).reshape(-1, 3).shape[0]
+        # what the kernels run (zero-padded weights) and where a residual is added: the library's own plan; the descriptor below
+        # carries the REFERENCE's widths, ds_system_create pads them the same way
+        self.device_dims, self.residuals = device_plan(self.hidden_dims, nf_in, nf,
+                                                       len(self.hidden_dims) - (0 if net_kw.get('use_last_layer', False) else 1))
         d = _lib.SystemDesc()
         keep = []                       # host arrays must outlive ds_system_create
 
@@ -114,7 +105,7 @@ class DeviceSystem:
             flat[:3 * n_sym] = np.asarray(src, dtype=np.float64).reshape(-1)
             getattr(d, name)[:] = flat.tolist()
         d.n_layers = len(self.hidden_dims)
-        for i, (a, b) in enumerate(self.device_dims):
+        for i, (a, b) in enumerate(self.hidden_dims):
             d.hidden_single[i], d.hidden_double[i] = a, b
         d.n_det = self.n_det
         d.distance_type = {'nu': 0, 'tri': 1}.get(net_kw.get('distance_type', 'nu'), 99)
@@ -595,6 +586,11 @@ class DeviceSystem:
         cnt = (C.c_int64 * n)()
         _lib.check(self.lib.ds_profile_read(self.handle, ms, cnt), 'ds_profile_read')
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(_lib.PROF_KINDS)}
+
+    def int8_layers(self):
+        """Number of dense hidden layers per local-energy evaluation whose per-electron contraction runs as an int8 split
+        (csrc/ds_i8.h; 0 with DS_NO_I8=1 or for shapes without an instance)."""
+        return int(self.lib.ds_int8_layers(self.handle))
 
     def profile_clock(self):
         """In-kernel clock probe of the hidden-layer kernel since profile(True): -> (shader cycles, 100 MHz reference ticks,

@@ -113,7 +113,7 @@ def learning_rate_schedule(rate=5e-2, decay=1.0, delay=10000.0):
 def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations, key=0, move_width=0.02, mcmc_steps=10,
                  burn_in=100, adapt_frequency=100, learning_rate=None, clip_local_energy=5.0, clip_type='real',
                  save_path=None, save_every=None, stats_file_name='train_stats', laplacian_mode='for',
-                 partition_number=3, t_init=0, opt_state=None, check_nan=True):
+                 partition_number=3, t_init=0, opt_state=None, check_nan=True, max_rejected=20):
     """The `optimizer='adam'` branch of the reference driver (process.py:204-219, 256-383): burn-in, then per iteration
     ``mcmc_step -> value_and_grad(total_energy) -> gradient pmean -> Adam -> CSV row -> width adaptation``, with
     checkpoints in the reference's layout (`deepsolid_amd.checkpoint.save`) every `save_every` iterations.
@@ -123,7 +123,9 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
     parameters and optimiser state keep their values, no CSV row is written for it (process.py:344), `rows` gets
     ``{'step': t, 'rejected': True, 'pmove': ...}`` and a warning is logged like the reference's (process.py:316).  A walker with a
     non-finite coordinate or non-finite parameters can never recover (the move is never accepted, the step never kept), so
-    after `max_rejected` = 20 rejections IN A ROW the loop raises instead of running to the end doing nothing."""
+    after `max_rejected` (default 20) rejections IN A ROW the loop writes a checkpoint of the last good state (walkers, parameters,
+    optimiser state: nothing of a rejected step was kept) and raises instead of running to the end doing nothing;
+    `max_rejected=None` is the reference's behaviour: log and go on (process.py:303-318)."""
     from . import checkpoint
     gen = _rank_generator(key, data.device, t_init)
     batch = data.shape[0]
@@ -145,7 +147,7 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
     if writer:
         writer.__enter__()
     t_last = t_init + iterations - 1
-    n_rejected, max_rejected = 0, 20
+    n_rejected = 0
     try:
         for t in range(t_init, t_init + iterations):
             data, params, opt_state, loss, aux, pmove, _ = step(t, data, params, opt_state, gen, width)
@@ -153,7 +155,9 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
                 rows.append({'step': t, 'rejected': True, 'pmove': float(pmove)})
                 n_rejected += 1
                 logging.warning('step %d: non-finite local energy / loss / gradient, step discarded (%d in a row)', t, n_rejected)
-                if n_rejected >= max_rejected:
+                if max_rejected is not None and n_rejected >= max_rejected:
+                    if save_path:
+                        checkpoint.save(save_path, t, data, params, opt_state, width)
                     raise FloatingPointError(f'{n_rejected} consecutive training steps were rejected for non-finite values '
                                              f'(last at step {t}): walkers or parameters are not finite')
             else:

@@ -147,18 +147,28 @@ def importance_update(params, f, x1, key, lp_1, num_accepts, latvec, stddev=0.02
     return x_new, key, lp_new, num_accepts
 
 
-_HOST_GENERATORS = {}
+import collections
+
+_HOST_GENERATORS = collections.OrderedDict()        # id(device generator) -> (generator, seed it was paired at, host generator); <= 8 entries
 
 
 def _host_generator(gen):
-    """CPU generator paired with a device generator (keyed by the object): seeded from the device generator's seed the first
-    time, then advanced on the host only -- drawing a key costs no device round trip."""
+    """CPU generator paired with a device generator: the Philox keys of the in-kernel noise are drawn from IT (no device round
+    trip per `mcmc_step`), not from the device generator's own stream.  It is seeded from `gen.initial_seed()` and re-created
+    whenever that seed changes, so `gen.manual_seed(s)` restarts the noise reproducibly; `set_state` on the device generator does
+    not (its state never drives the noise).  torch generators cannot be weakly referenced: the cache keeps the eight most
+    recently used pairs."""
+    seed = int(gen.initial_seed()) & (2 ** 63 - 1)
     g = _HOST_GENERATORS.get(id(gen))
-    if g is None or g[0] is not gen:
+    if g is None or g[0] is not gen or g[1] != seed:
         h = torch.Generator(device='cpu')
-        h.manual_seed(int(gen.initial_seed()) & (2 ** 63 - 1))
-        _HOST_GENERATORS[id(gen)] = g = (gen, h)
-    return g[1]
+        h.manual_seed(seed)
+        g = (gen, seed, h)
+    _HOST_GENERATORS[id(gen)] = g
+    _HOST_GENERATORS.move_to_end(id(gen))
+    while len(_HOST_GENERATORS) > 8:
+        _HOST_GENERATORS.popitem(last=False)
+    return g[2]
 
 
 def make_mcmc_step(batch_slog_network, batch_per_device, latvec, steps=10, atoms=None,

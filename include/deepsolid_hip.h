@@ -58,8 +58,8 @@ typedef struct ds_system_desc {
     double sim_AV[DS_MAX_SYM * 3], sim_BV[DS_MAX_SYM * 3];
     /* network */
     int32_t n_layers;            /* len(hidden_dims) */
-    int32_t hidden_single[DS_MAX_LAYERS];
-    int32_t hidden_double[DS_MAX_LAYERS];
+    int32_t hidden_single[DS_MAX_LAYERS];   /* the REFERENCE's hidden_dims[l][0] verbatim (network.py:111-132): 1..1024 */
+    int32_t hidden_double[DS_MAX_LAYERS];   /* ... hidden_dims[l][1]: 1..32.  The library pads both internally (ds_device_widths) */
     int32_t n_det;               /* determinants */
     int32_t distance_type;       /* 0 = 'nu' (network.py:207), 1 = 'tri' (network.py:227; isotropic envelope only) */
     int32_t envelope_type;       /* 0 = 'isotropic' (network.py:335), 1 = 'diagonal' (:340), 2 = 'full' (:358) */
@@ -105,9 +105,26 @@ typedef struct ds_param_block {
     int32_t rows, cols;
 } ds_param_block;
 
+/* The widths the kernels run for the reference's hidden_dims, and where a residual is added (host code, needs no GPU).
+ * One-electron widths are zero-padded to multiples of 64, pair widths to 16 or 32 -- exact: a padded feature is tanh(0) = 0 in
+ * every layer and meets zero rows in the next.  res_single[l] / res_double[l] = 1 where the reference adds a residual
+ * (network.py:525-528: input width == output width of the REFERENCE's widths), independent of the padded widths.
+ * n_in_single / n_in_double: widths of the input features (nf * atoms, nf; nf = 4 for 'nu', 7 for 'tri'); n_double: pair layers
+ * that run (n_layers - 1, or n_layers with use_last_layer).  ds_system_create applies exactly this to its descriptor;
+ * ds_param_layout reports the PADDED block shapes: a caller copies each reference block into the top-left corner of its
+ * padded segments ([h | pair-up | pair-dn] rows of W_loc, [mean-up | mean-dn] rows of W_sh, ...) and leaves the rest zero. */
+int ds_device_widths(const int32_t* hidden_single, const int32_t* hidden_double, int32_t n_layers, int32_t n_in_single,
+                     int32_t n_in_double, int32_t n_double, int32_t* dev_single, int32_t* dev_double, int32_t* res_single,
+                     int32_t* res_double);
+
 int ds_system_create(const ds_system_desc* desc, ds_system** out);
 void ds_system_destroy(ds_system* sys);
 const char* ds_last_error(void);
+
+/* Number of dense hidden one-electron layers per local-energy evaluation whose per-electron contraction runs as an error-free
+ * split on the int8 matrix pipe (csrc/ds_i8.h: float64 in, float64 out; 5-slot-tile float64 cells with 256 features).
+ * 0 when the library was loaded with DS_NO_I8=1 or the architecture has no instance. */
+int ds_int8_layers(const ds_system* sys);
 
 int64_t ds_param_count(const ds_system* sys);
 /* fills up to `max_blocks` entries, returns the number of blocks */

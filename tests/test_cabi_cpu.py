@@ -116,8 +116,8 @@ def test_shape_limits_are_rejected_at_create():
     """Every shape the kernels cannot run is refused by ds_system_create itself (check_arch runs before any device
     allocation, so this needs no GPU): a handle that was created never fails at its first launch.  The supported set is
     documented in DESIGN.md section 1: determinant matrices up to 64 x 64 (hence N <= 128 electrons, or 64 with full_det:
-    jet-slot tiles 1..25 all have kernel instances), hidden_single multiples of 64 up to 1024, hidden_double 16 or 32, up to 64
-    determinants."""
+    jet-slot tiles 1..25 all have kernel instances), the reference's hidden_dims verbatim with one-electron widths 1..1024 and pair
+    widths 1..32 (padded inside the library), up to 64 determinants."""
     import ctypes as C
     from deepsolid_amd import _lib
     lib = _lib.load()
@@ -147,9 +147,14 @@ def test_shape_limits_are_rejected_at_create():
     # (1..25 slot tiles, csrc/ds_tiles.h) -- these descriptors pass every shape check and are refused only for their missing arrays
     for n_up, n_dn in ((30, 30), (41, 40), (54, 54), (64, 64)):
         assert 'null array' in err(n_up=n_up, n_dn=n_dn)
-    assert 'hidden_single' in err(hidden_single=[256, 200, 256])
+    # the descriptor carries the REFERENCE's widths: 200 or 24 are fine (zero-padded inside), refused are widths beyond the kernels'
+    # range and a first layer as wide as its input features (the reference's residual there, network.py:525-528)
+    assert 'null array' in err(hidden_single=[256, 200, 256], hidden_double=[32, 24, 32])
     assert 'hidden_single' in err(hidden_single=[2048, 256, 256])
-    assert 'hidden_double' in err(hidden_double=[32, 24, 32])
+    assert 'hidden_single' in err(hidden_single=[256, 0, 256])
+    assert 'hidden_double' in err(hidden_double=[32, 40, 32])
+    assert 'residual' in err(hidden_single=[4, 256, 256])            # n_atoms_prim = 1, 'nu': 4 input features
+    assert 'residual' in err(hidden_double=[4, 32, 32])
     assert 'n_det' in err(n_det=65)
     assert 'n_up' in err(n_up=0)
     assert 'n_dn' in err(n_dn=-1)

@@ -167,16 +167,16 @@ def test_energy_gradient_vs_oracle(clip_type, clip):
     assert_tree_close(grads, g_ref, 1e-7)
 
 
-@pytest.mark.parametrize('hidden_dims,use_last', [(((40, 10), (56, 12), (56, 12)), False), (((100, 20), (100, 20)), True)])
+@pytest.mark.parametrize('hidden_dims,use_last', [(((40, 10), (56, 12), (56, 12)), False), (((100, 20), (100, 20)), True),
+                                                  (((64, 20), (64, 24), (64, 24)), False)])
 def test_hidden_widths_without_kernel_instances(hidden_dims, use_last):
     """Widths the kernels have no instance for (one-electron widths that are not multiples of 64, pair widths other than 16 / 32)
-    run with zero-padded weights (deepsolid_amd/device.py::device_widths): exact, because a padded feature is tanh(0) = 0 in every
-    layer.  The residual connections must follow the REFERENCE widths (network.py:525-528): 40 -> 56 has none although both pad
-    to 64 (the second becomes 128), 56 -> 56 has one; 10 -> 12 has none (16 and 32), 12 -> 12 has one.  Loss, local energies and
-    the energy gradient -- mapped back to the reference's parameter shapes -- against the oracle; the same tree must be refused
-    where no padding can keep two different pair widths apart."""
+    run with zero-padded weights (the library's own plan: ds_device_widths, deepsolid_amd/device.py::device_plan): exact, because a
+    padded feature is tanh(0) = 0 in every layer.  The residual connections follow the REFERENCE widths (network.py:525-528) through
+    explicit flags: 40 -> 56 has none although both pad to 64, 56 -> 56 has one; 10 -> 12 has none (both 16), 12 -> 12 has one;
+    20 -> 24 has none although both run the 32-wide pair kernels (refused until round 5).  Loss, local energies and the energy
+    gradient -- mapped back to the reference's parameter shapes -- against the oracle."""
     from deepsolid_amd import network as dnet, train as dtrain
-    from deepsolid_amd.device import device_widths
     from oracle.testing import make_test_params
     cell, klist = systems.build('lih')
     net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=hidden_dims, use_last_layer=use_last)
@@ -192,8 +192,6 @@ def test_hidden_widths_without_kernel_instances(hidden_dims, use_last):
     assert abs(float(loss) - float(l_ref)) < 1e-8
     assert float((aux.local_energy.cpu() - aux_ref.local_energy).abs().max()) < 1e-8
     assert_tree_close(grads, g_ref, 1e-7)
-    with pytest.raises(ValueError):
-        device_widths(((64, 20), (64, 24), (64, 24)), 4)
 
 
 def test_forty_determinants():

@@ -306,41 +306,6 @@ def test_energy_stats_and_nonfinite_count():
     assert float(aux.n_nonfinite) == 0.0 and np.isfinite(float(loss))
 
 
-def test_two_stream_chunk_pipelining_is_bit_identical(tmp_path):
-    """DS_STREAMS=2 (two half-size workspaces, chunks alternating between two side streams; read once in
-    ds_system_create, so it needs its own process): every walker's energy is computed by the same kernels on the same
-    data, so the result must equal the single-stream result bit for bit."""
-    import os
-    import subprocess
-    import sys
-    from deepsolid_amd import hamiltonian, systems
-    fx, cell, klist, net_kw, params = load_case('bcc_li')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / 'two_streams.py'
-    out = tmp_path / 'ke.pt'
-    script.write_text(f'''
-import sys, torch
-sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, "tests")!r})
-from common import load_case
-from deepsolid_amd import hamiltonian, network, systems
-fx, cell, klist, net_kw, params = load_case('bcc_li')
-dp = {{k: [{{kk: torch.as_tensor(vv, dtype=torch.float64, device='cuda') for kk, vv in d.items()}} for d in v] for k, v in params.items()}}
-net = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
-x = torch.as_tensor(systems.synthetic_walkers(cell, 300, seed=21), device='cuda')
-ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(dp, x)
-torch.save((torch.view_as_real(ke).cpu(), ew.cpu()), {str(out)!r})
-''')
-    env = dict(os.environ, DS_STREAMS='2')
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
-    ke2, ew2 = torch.load(out)
-    dp = dev_params(params)
-    (net,) = nets(cell, klist, net_kw, 'eval_logdet')
-    x = torch.as_tensor(systems.synthetic_walkers(cell, 300, seed=21), device='cuda')
-    ke, ew = hamiltonian.local_energy_seperate(net.apply, cell)(dp, x)
-    assert torch.equal(torch.view_as_real(ke).cpu(), ke2) and torch.equal(ew.cpu(), ew2)
-
-
 def test_bench_under_torchrun_with_rccl_one_rank():
     """The driver's launch line (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) with N = 1 on the
     GPU box: the process group is RCCL (backend "nccl"), the packed statistics go through a real all-reduce on the device, and

@@ -371,30 +371,45 @@ def test_klist_from_a_saved_hf_run(tmp_path):
         np.testing.assert_allclose(ph, np.exp(2j * np.pi * t) * np.ones(len(ph)), atol=1e-12)
 
 
-def test_device_widths_keep_the_reference_residual_pattern():
-    """deepsolid_amd/device.py::device_widths: the widths the kernels run for the reference's hidden_dims (zero-padded weights, exact).
-    One-electron widths become multiples of 64, pair widths 16 or 32, and two consecutive padded widths are equal exactly where
-    the reference's are (network.py:525-528 adds a residual when in == out; the library reads that off the widths it is given)."""
+def test_device_plan_follows_the_reference_residual_pattern():
+    """deepsolid_amd/device.py::device_plan = the C ABI's ds_device_widths (host code, runs without a GPU): the widths the kernels
+    run for the reference's hidden_dims (zero-padded weights, exact) and an EXPLICIT residual flag per layer and stream, set exactly
+    where the reference adds a residual (network.py:525-528: in == out of the reference's widths) -- also at layer 0, where a width
+    equal to the input features' is refused unless the kernels can run the residual."""
     import itertools
-    from deepsolid_amd.device import device_widths
+    from deepsolid_amd.device import device_plan, device_widths
     assert device_widths(((256, 32),) * 3, 4) == ((256, 32),) * 3
     assert device_widths(((100, 20),) * 3, 4) == ((128, 32),) * 3
-    assert device_widths(((100, 10), (120, 12), (120, 12)), 4) == ((128, 16), (192, 32), (192, 32))
-    assert device_widths(((64, 16), (64, 16)), 64) == ((64, 16), (64, 16))          # the input width itself is 64: a residual at layer 0
-    assert device_widths(((64, 16), (64, 16)), 62) == ((128, 16), (128, 16))        # 62 input rows pad to 64, but 62 != 64: none
-    assert device_widths(((256, 32), (256, 32), (256, 24)), 4, n_double=2) == ((256, 32),) * 3      # the last pair width is unused
-    with pytest.raises(ValueError):
-        device_widths(((64, 20), (64, 24), (64, 24)), 4)       # 20 -> 24 without a residual, both need the 32-wide kernels
-    with pytest.raises(ValueError):
-        device_widths(((64, 40), (64, 40)), 4)                 # pair widths beyond 32
+    dev, res = device_plan(((100, 10), (120, 12), (120, 12)), 4)
+    assert dev == ((128, 16), (128, 16), (128, 16)) and res == ((False, False), (False, False), (True, True))
+    dev, res = device_plan(((40, 10), (56, 12), (56, 12)), 8)          # 40 -> 56 pads to 64 -> 64 and still has no residual
+    assert dev == ((64, 16),) * 3 and res == ((False, False), (False, False), (True, True))
+    dev, res = device_plan(((64, 20), (64, 24), (64, 24)), 4)          # (refused until round 5: two different 32-wide pair widths)
+    assert dev == ((64, 32),) * 3 and res == ((False, False), (True, False), (True, True))
+    dev, res = device_plan(((64, 16), (64, 16)), 64)                   # the input width itself is 64: a residual at layer 0
+    assert dev == ((64, 16), (64, 16)) and res == ((True, False), (True, True))
+    assert device_plan(((64, 16), (64, 16)), 62)[1][0] == (False, False)        # 62 input rows pad to 64, but 62 != 64: none
+    dev, res = device_plan(((256, 32), (256, 32), (256, 24)), 4, n_double=2)    # the last pair width is unused
+    assert dev[:2] == ((256, 32),) * 2 and dev[2][0] == 256 and res[2] == (True, False)
+    for bad, n_in, n_in2 in ((((64, 40), (64, 40)), 4, 4),              # pair widths beyond 32
+                             (((2048, 16), (64, 16)), 4, 4),            # one-electron widths beyond 1024
+                             (((8, 16), (8, 16)), 8, 4),                # layer 0 as wide as its 8 input features: the reference's residual
+                             (((64, 4), (64, 4)), 4, 4),                # ... of the pair stream ('nu': 4 features)
+                             (((64, 7), (64, 7)), 7, 7)):               # ... ('tri': 7 features)
+        with pytest.raises(ValueError):
+            device_plan(bad, n_in, n_in2)
     singles, pairs = (40, 64, 100, 128, 130), (8, 16, 20, 32)
-    for dims in itertools.product(itertools.product(singles, pairs), repeat=3):
-        try:
-            dev = device_widths(dims, 4)
-        except ValueError:
-            continue
-        for l, ((a, b), (pa, pb)) in enumerate(zip(dims, dev)):
-            assert pa % 64 == 0 and pa >= a and pb in (16, 32) and pb >= b
-            if l:
-                assert (a == dims[l - 1][0]) == (pa == dev[l - 1][0])
-                assert (b == dims[l - 1][1]) == (pb == dev[l - 1][1])
+    for n_in, n_in2 in ((4, 4), (64, 4), (128, 7), (40, 7)):
+        for dims in itertools.product(itertools.product(singles, pairs), repeat=3):
+            try:
+                dev, res = device_plan(dims, n_in, n_in2)
+            except ValueError:
+                assert dims[0][0] == n_in and n_in % 64, (dims, n_in)     # the only refusal inside this grid
+                continue
+            for l, ((a, b), (pa, pb), (r1, r2)) in enumerate(zip(dims, dev, res)):
+                assert pa % 64 == 0 and pa >= a and pa - a < 64 and pb in (16, 32) and pb >= b
+                assert r1 == (a == (dims[l - 1][0] if l else n_in)) and r2 == (b == (dims[l - 1][1] if l else n_in2))
+                if l and r1:
+                    assert pa == dev[l - 1][0]
+                if l and r2:
+                    assert pb == dev[l - 1][1]
