@@ -276,19 +276,41 @@ __global__ void __launch_bounds__(512, 1) k_layer_i8(const double* __restrict__ 
         double* Go = Gout + (size_t)tile * tile_stride + lr_e;
         // The workgroup is alone on its CU and its waves reach this point together: nothing hides a load's latency here, and with
         // global -> LDS loads in flight every wait is a wait for everything, so a deeper software pipeline would buy nothing.
-        // One half (16 rows) at a time: its 20 shared-term and 20 residual loads per lane go out together.  (Both halves' loads in
-        // one or two volleys with a hand-written epilogue: 284-468 bytes of scratch per lane, 20.8 ms instead of 17.9.)
+        // One half (16 rows) at a time: its 20 shared-term and 20 residual loads per lane go out together, one round trip per half
+        // (the residual + store stage of layer_epilogue is handed in).  (Both halves' loads in one or two volleys with a
+        // hand-written epilogue: 284-468 bytes of scratch per lane, 20.8 ms instead of 17.9.)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             acc_t zh[1][ST];
+            double sv[4][ST], hv[4][ST], sw[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 16 * q + acc_row<double>(lane_e, r);
-                const double sw = SW[n];
+                sw[r] = SW[n];
 #pragma unroll
-                for (int s = 0; s < ST; ++s) zh[0][s][r] = fma(zacc[q][s][r], sw, Sp[(size_t)n * P + 16 * s]);
+                for (int s = 0; s < ST; ++s) {
+                    sv[r][s] = Sp[(size_t)n * P + 16 * s];
+                    if (EPI == 2) hv[r][s] = Gi[(size_t)n * P + 16 * s];
+                }
             }
-            layer_epilogue<double, 1, ST, EPI, 0>(zh, Gi, Go, (const double*)nullptr, n0 + 16 * q, lane_e, P);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < ST; ++s) zh[0][s][r] = fma(zacc[q][s][r], sw[r], sv[r][s]);
+            if (EPI == 2) {
+                // (residual + store stage of layer_epilogue: the residual rows were requested with the shared term above)
+                auto rf = [&](int) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + 16 * q + acc_row<double>(lane_e, r);
+#pragma unroll
+                        for (int s = 0; s < ST; ++s)
+                            __builtin_nontemporal_store((hv[r][s] + zh[0][s][r]) * 0.70710678118654752440, &Go[(size_t)n * P + 16 * s]);
+                    }
+                };
+                layer_epilogue<double, 1, ST, 2, 0>(zh, (const double*)nullptr, Go, (const double*)nullptr, n0 + 16 * q, lane_e, P, rf);
+            } else
+                layer_epilogue<double, 1, ST, 1, 0>(zh, (const double*)nullptr, Go, (const double*)nullptr, n0 + 16 * q, lane_e, P);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)

@@ -14,13 +14,26 @@ EWALD_GMAX = 200          # reference ewaldsum.py:34
 WEIGHT_CUTOFF = 1e-12     # reference ewaldsum.py:199
 
 
-def _half_space_mesh(recvec, cellvolume, alpha, gmax):
+def _half_space_mesh(recvec, cellvolume, alpha, gmax, latvec=None):
     """G vectors with x>0, or x=0,y>0, or x=y=0,z>0 and weight above the cutoff
     (reference ewaldsum.py:67-89,194-200).  Order = the reference's: the three
-    groups concatenated, each in C order of its integer mesh.  Evaluated in
-    slabs of the first index so the 3.2e7-candidate scan stays small in memory."""
-    full = np.arange(-gmax, gmax + 1)
-    pos = np.arange(1, gmax + 1)
+    groups concatenated, each in C order of its integer mesh.
+
+    The reference scans all (2 gmax + 1)^3 / 2 = 3.2e7 integer triples; the weight falls monotonically with |G|^2, so only
+    triples inside the sphere w(|G|^2) = cutoff can pass, and n_j = G . a_j / 2 pi bounds each integer by |G|max |a_j| / 2 pi:
+    the scan runs over that box only (same points, same order: a sub-box of a C-ordered mesh keeps the order of what it keeps)."""
+    lo, hi = 0.0, 1.0
+    wfun = lambda g2: 4 * np.pi * np.exp(-g2 / (4 * alpha ** 2)) / (cellvolume * g2)
+    while wfun(hi) > WEIGHT_CUTOFF:
+        hi *= 2.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if wfun(mid) > WEIGHT_CUTOFF else (lo, mid)
+    gm = np.sqrt(hi) * (1 + 1e-9)
+    if latvec is None:
+        latvec = np.linalg.inv(recvec).T
+    nmax = [int(min(gmax, np.floor(gm * np.linalg.norm(latvec[j]) / (2 * np.pi)) + 1)) for j in range(3)]
+    fy, fz = np.arange(-nmax[1], nmax[1] + 1), np.arange(-nmax[2], nmax[2] + 1)
     pts, wts = [], []
 
     def scan(ix, iy, iz):
@@ -34,10 +47,10 @@ def _half_space_mesh(recvec, cellvolume, alpha, gmax):
             pts.append(g[keep])
             wts.append(w[keep])
 
-    for x0 in range(1, gmax + 1, 8):
-        scan(np.arange(x0, min(x0 + 8, gmax + 1)), full, full)
-    scan(np.array([0]), pos, full)
-    scan(np.array([0]), np.array([0]), pos)
+    for x0 in range(1, nmax[0] + 1, 8):
+        scan(np.arange(x0, min(x0 + 8, nmax[0] + 1)), fy, fz)
+    scan(np.array([0]), np.arange(1, nmax[1] + 1), fz)
+    scan(np.array([0]), np.array([0]), np.arange(1, nmax[2] + 1))
     return np.concatenate(pts, axis=0), np.concatenate(wts, axis=0)
 
 
@@ -53,7 +66,7 @@ class EwaldTables:
         volume = np.linalg.det(self.latvec)
         recvec = np.linalg.inv(self.latvec).T
         self.alpha = 5.0 / np.amin(1.0 / np.linalg.norm(recvec, axis=1))          # :63-64
-        self.gpoints, self.gweight = _half_space_mesh(recvec, volume, self.alpha, ewald_gmax)
+        self.gpoints, self.gweight = _half_space_mesh(recvec, volume, self.alpha, ewald_gmax, self.latvec)
         q = self.atom_charges
         self.i_sum = q.sum()
         ii_sum2 = (q ** 2).sum()
