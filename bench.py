@@ -102,12 +102,14 @@ def cpu_model():
 def _cpu_worker(job):
     """One of the concurrent processes of the all-cores CPU baseline: `reps` fori_loop iterations (hamiltonian.py:59-66) on the
     vmapped sample with `threads` torch threads; -> seconds per iteration."""
-    cell, klist, net_kw, params_np, xs_np, threads, reps = job
+    system, net_kw, params_np, xs_np, threads, reps = job
     import torch as _t
     from torch.func import vmap
+    from deepsolid_amd import systems
     from oracle import hamiltonian as oham
     from oracle import network as onet
     _t.set_num_threads(threads)
+    cell, klist = systems.build(system)                 # (host-side cell builder: no GPU; the parent's objects do not pickle)
     net = onet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
     p = onet.params_to_torch(params_np)
     xs = _t.as_tensor(xs_np)
@@ -119,18 +121,31 @@ def _cpu_worker(job):
     return (time.perf_counter() - t0) / reps
 
 
-def cpu_all_cores(cell, klist, net_kw, params_np, xs_np, t_dir_single, value_single, threads=16, max_procs=4):
+def cpu_all_cores(system, net_kw, params_np, xs_np, t_dir_single, value_single, threads=16, max_procs=4):
     """The same CPU restatement on MORE of the host: `n` processes x `threads` threads side by side, each on the whole sample
     (torch's intra-op pool does not scale past ~16 threads on these small contractions, processes do).  The aggregate is
-    n x the single-process rate divided by the slow-down of an iteration under that load."""
+    n x the single-process rate divided by the slow-down of an iteration under that load.  The processes are plain
+    `python bench.py --cpu-worker JOB` children with a deadline: whatever happens to them, the bench line is printed."""
+    import pickle
+    import subprocess
+    import tempfile
     n = max(1, min(max_procs, (os.cpu_count() or 1) // threads))
     if n < 2:
         return None
+    procs, path = [], None
     try:
-        import torch.multiprocessing as mp
         reps = max(1, min(3, int(6.0 / max(t_dir_single, 1e-3))))
-        with mp.get_context('spawn').Pool(n) as pool:
-            ts = pool.map(_cpu_worker, [(cell, klist, net_kw, params_np, xs_np, threads, reps)] * n)
+        with tempfile.NamedTemporaryFile(suffix='.pkl', delete=False) as f:
+            pickle.dump((system, dict(net_kw), params_np, xs_np, threads, reps), f)
+            path = f.name
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', path], stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(n)]
+        deadline = time.time() + max(120.0, 30.0 * t_dir_single * reps)
+        ts = []
+        for pr in procs:
+            out, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+            ts.append(float([l for l in out.splitlines() if l.startswith('CPU_WORKER ')][-1].split()[1]))
         slow = max(ts) / t_dir_single
         return dict(value=n * value_single / max(slow, 1.0), processes=n, threads_per_process=threads, cores=n * threads,
                     slowdown_per_iteration=slow,
@@ -139,9 +154,15 @@ def cpu_all_cores(cell, klist, net_kw, params_np, xs_np, t_dir_single, value_sin
     except Exception as e:                                  # the baseline is a courtesy number: never fail the bench line over it
         log(f'all-cores cpu baseline skipped: {e!r}')
         return None
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        if path and os.path.exists(path):
+            os.unlink(path)
 
 
-def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walkers=64):
+def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walkers=64, system=None):
     """Reference-algorithm CPU restatement (JAX is not installable here or on the GPU box; SURVEY 8(d) protocol).
 
     `for` (the reference default, hamiltonian.py:45-70): `walkers` walkers batched with torch.func.vmap the way
@@ -194,7 +215,7 @@ def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walk
     for b in range(1, min(4, x_np.shape[0])):
         xb = torch.as_tensor(x_np[b])
         errs.append(abs(complex(e_gpu[b]) - (complex(ofl.stages(p, xb, klist, cell, net_kw)['ke']) + float(ew(xb)))))
-    allc = cpu_all_cores(cell, klist, net_kw, params_np, xs.numpy(), t_dir, nw / t_for, threads=cores)
+    allc = cpu_all_cores(system, net_kw, params_np, xs.numpy(), t_dir, nw / t_for, threads=cores) if system else None
     return dict(value=nw / t_for, unit='local-energy evals/s', cores=cores, kind='port', cpu=cpu_model(),
                 mode='for', hessian_mode_value=nh / t_h, all_cores=allc, host_threads=os.cpu_count(),
                 sample=f'{nw} walkers under torch.func.vmap; '
@@ -264,8 +285,15 @@ def main():
     ap.add_argument('--single-scaling', action='store_true', help='N > 1: measure only --scaling, not the other mode beside it')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher / reduction plumbing only (no GPU work): every rank reports in, rank 0 prints the JSON line')
+    ap.add_argument('--cpu-worker', default=None, help=argparse.SUPPRESS)       # child process of the all-cores CPU baseline
     args = ap.parse_args()
 
+    if args.cpu_worker:
+        import pickle
+        with open(args.cpu_worker, 'rb') as f:
+            job = pickle.load(f)
+        print(f'CPU_WORKER {_cpu_worker(job):.6f}', flush=True)
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
     rank = int(os.environ.get('RANK', 0))
@@ -532,7 +560,7 @@ def main():
         roofline['traffic_detail'] = hidden_obj['traffic_detail'] = tr
     if world == 1 and not args.no_cpu_baseline:
         params_np = {k: [{kk: vv.cpu().numpy() for kk, vv in d.items()} for d in v] for k, v in params.items()}
-        cb, err = cpu_baseline(cell, klist, net_kw, params_np, x_np, aux.local_energy[:64].cpu().numpy(), args.cpu_seconds)
+        cb, err = cpu_baseline(cell, klist, net_kw, params_np, x_np, aux.local_energy[:64].cpu().numpy(), args.cpu_seconds, system=args.system)
         out['cpu_baseline'] = cb
         out['max_abs_err_ha'] = float(err)
     else:

@@ -419,7 +419,7 @@ inline bool lowrank_possible(const ds_system* s, int ST) {
 inline bool int8_layer(const ds_system* s, int l) {
     const ds::SysDev<double>& S = s->sd;
     const int Kloc = S.h1[l] + S.nch * S.h2[l];
-    return s->dtype == 0 && s->use_i8 && l >= 1 && s->res1[l] && S.P == ds::i8::P && S.h1[l + 1] == ds::i8::NOUT && (Kloc == 256 || Kloc == 320);
+    return s->dtype == 0 && s->use_i8 && l >= 1 && s->res1[l] && S.P == ds::i8::P && S.h1[l + 1] == ds::i8::NOUT && Kloc == 320;
 }
 
 // The forward-Laplacian chain on a chunk of Bc walkers.
@@ -558,12 +558,8 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 hipLaunchKernelGGL(ds::i8::k_i8_prep_w, dim3(ds::i8::NOUT / 16), dim3(256), 0, st, (const double*)blk(s->i_wloc[l]), Kloc, Nout, wp, sw);
                 const int ntiles = (int)(Bc * S.N);
                 const dim3 igrid((unsigned)std::min<int64_t>(Bc, s->n_cu));
-                if (Kloc == 320)
-                    hipLaunchKernelGGL((ds::i8::k_layer_i8<5, 2>), igrid, dim3(512), ds::i8::lds_bytes(), st, (const double*)c.G[gi], gts, (const uint4*)wp,
-                                       (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
-                else
-                    hipLaunchKernelGGL((ds::i8::k_layer_i8<4, 2>), igrid, dim3(512), ds::i8::lds_bytes(), st, (const double*)c.G[gi], gts, (const uint4*)wp,
-                                       (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
+                hipLaunchKernelGGL((ds::i8::k_layer_i8<5, 2>), igrid, dim3(512), ds::i8::lds_bytes(), st, (const double*)c.G[gi], gts, (const uint4*)wp,
+                                   (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
             } else if (res) {
                 ga.oe.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }

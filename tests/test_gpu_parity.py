@@ -365,6 +365,39 @@ def test_int8_split_hidden_layer_vs_float64_kernel(no_lowrank, monkeypatch):
     assert 0 < np.abs(g3[None] - g3['1']).max() < 1e-11 * np.abs(g3['1']).max()       # different arithmetic (not the same kernel twice), same numbers
 
 
+@pytest.mark.parametrize('nelec,hidden_dims', [((13, 13), ((256, 32),) * 3),          # 80 of 80 jet slots used: no padded column
+                                               ((11, 10), ((256, 32),) * 3),          # 65 of 80: fifteen all-zero columns (scale of an empty column)
+                                               ((24, 0), ((256, 32),) * 3),           # one spin channel: K = 288 is not five whole chunks -> float64 kernel
+                                               ((12, 12), ((256, 16),) * 4)])         # 16-wide pairs: K = 288 again, four layers
+def test_int8_split_layer_other_shapes_vs_oracle(nelec, hidden_dims, monkeypatch):
+    """The int8 hidden layer (csrc/ds_i8.h) on the other shapes that reach it -- electron counts with 5 jet-slot tiles other than
+    24, with and without padded slot columns -- and on shapes that must NOT reach it (K = 256 + nch x pair width has to be 320),
+    against the forward-Laplacian oracle and against the float64 kernel; `ds_int8_layers` says which path ran."""
+    from deepsolid_amd import systems
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('bcc_li', nelec=nelec)
+    net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=hidden_dims)
+    params = make_test_params(93, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    dp = dev_params(params)
+    x64 = systems.synthetic_walkers(cell, 2, seed=10)
+    x = torch.as_tensor(x64, device='cuda')
+    ref = complex(ofl.stages(onet.params_to_torch(params), tt(x64[0]), klist, cell, net_kw)['ke'])
+    monkeypatch.delenv('DS_NO_I8', raising=False)
+    sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
+    nch = 2 if nelec[1] else 1
+    kloc = [h[0] + nch * h[1] for h in hidden_dims]
+    # hidden layers l >= 2 (layer 1 is the low-rank kernel) whose input has K = 320 rows and 256 features in and out
+    expect = sum(1 for l in range(2, len(hidden_dims)) if kloc[l - 1] == 320 and hidden_dims[l - 1][0] == 256 and hidden_dims[l][0] == 256)
+    assert sysd.int8_layers() == expect, (sysd.int8_layers(), expect)
+    ke = torch.view_as_complex(sysd.local_energy(dp, x)[0]).cpu().numpy()
+    assert abs(ke[0] - ref) < 1e-9 * max(1.0, abs(ref)), (ke[0], ref)
+    monkeypatch.setenv('DS_NO_I8', '1')
+    ke64 = torch.view_as_complex(DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).local_energy(dp, x)[0]).cpu().numpy()
+    assert np.abs(ke - ke64).max() < 5e-10 * max(1.0, np.abs(ke64).max())
+
+
 @pytest.mark.parametrize('hidden_dims,nelec', [(((256, 32), (128, 16), (192, 32)), None),        # layer 1 without a residual connection
                                                (((128, 16), (128, 16), (128, 16)), None),        # narrow streams
                                                (((256, 32), (256, 32), (256, 32)), (24, 0))])    # one spin channel
