@@ -6,6 +6,7 @@ TAG=${1:-r02}
 set -x
 mkdir -p gpurun_out/final_$TAG
 F=gpurun_out/final_$TAG
+python -m pytest tests -m gpu -q -k "int8" 2>&1 | tail -2 > $F/int8_tests.txt
 python bench.py > $F/bench.json 2> $F/bench.err
 tail -c 900 $F/bench.json
 bash tools/profile_bench.sh ${TAG}_bench > $F/prof.txt 2>&1
