@@ -557,7 +557,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 double* sw = (double*)(wp + ds::i8::wp_bytes(64 * 5));
                 hipLaunchKernelGGL(ds::i8::k_i8_prep_w, dim3(ds::i8::NOUT / 16), dim3(256), 0, st, (const double*)blk(s->i_wloc[l]), Kloc, Nout, wp, sw);
                 const int ntiles = (int)(Bc * S.N);
-                const dim3 igrid((unsigned)std::min<int64_t>(Bc, s->n_cu));
+                const dim3 igrid((unsigned)std::min<int64_t>(ntiles, s->n_cu));
                 hipLaunchKernelGGL((ds::i8::k_layer_i8<5, 2>), igrid, dim3(512), ds::i8::lds_bytes(), st, (const double*)c.G[gi], gts, (const uint4*)wp,
                                    (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
             } else if (res) {

@@ -35,6 +35,10 @@ constexpr int P = 80, ST = 5;                           // jet slots of the inst
 constexpr int CH16 = NPL * 4 * P;                       // 16-byte pieces of a chunk's planes (1920 = 30720 bytes)
 constexpr int CHI = (CH16 + P / 2 + 63) / 64 * 64;      // ... of a chunk image in LDS: planes + the 80 column scales (1984)
 constexpr int NOUT = 256;
+// cache policy of the raw-tile stream (global -> LDS); 2 = non-temporal measured no different (same fabric bytes, 17.7 against 17.6 ms)
+#ifndef DS_I8_RAW_AUX
+#define DS_I8_RAW_AUX 0
+#endif
 inline size_t lds_bytes() { return 2 * ((size_t)CHI * 16 + 64 * P * 8) + 2 * P * 4; }
 inline size_t wp_bytes(int K) { return (size_t)K * NOUT * NPL; }
 
@@ -167,7 +171,7 @@ __device__ __forceinline__ void slice_chunk(const double* __restrict__ R, const 
 
 // The layer.  X: input tiles [tile][ldx rows][P] (the first 64 NCH rows are contracted, rows 0 .. 255 are the residual);
 // Sb: shared term + bias [walker][256][P] (walker = tile / N); Gout: output tiles, same strides.  EPI = 2: residual layer
-// (h_out = (h_in + tanh-chain(z)) / sqrt 2), EPI = 1: no residual.  grid = min(walkers, CUs), block = 512, LDS = lds_bytes(); ntiles = walkers x N.
+// (h_out = (h_in + tanh-chain(z)) / sqrt 2), EPI = 1: no residual.  grid = CUs (a multiple of 8 for the XCD-aware tile order; fewer when there are fewer tiles), block = 512, LDS = lds_bytes(); ntiles = walkers x N.
 template <int NCH, int EPI>
 __global__ void __launch_bounds__(512, 1) k_layer_i8(const double* __restrict__ X, size_t tile_stride, const uint4* __restrict__ WP,
                                                      const double* __restrict__ SW, const double* __restrict__ Sb, int N,
@@ -178,11 +182,19 @@ __global__ void __launch_bounds__(512, 1) k_layer_i8(const double* __restrict__ 
     uint32_t* const MXb = reinterpret_cast<uint32_t*>(Rb + 2 * 64 * P);       // 2 x 80 column maxima (high words)
     constexpr int nf16 = NOUT / 16;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lq = lane >> 4, lr = lane & 15;
-    // this workgroup's tiles: WALKERS blockIdx.x, + gridDim.x, ... with their N electron tiles back to back (the walker's shared term
-    // then comes from the L2 for 23 of its 24 tiles)
+    // This workgroup's tiles.  Workgroup ids b, b + 8, ... share an XCD (its L2): XCD x = b % 8 takes the walkers w = x (mod 8) and
+    // deals their electron tiles, in order, to its gridDim.x / 8 workgroups -- at any time the CUs of an XCD work on the ~1.3 walkers
+    // whose shared term S (164 KB each) then sits in that L2 once.  (Tiles of a walker back to back on ONE workgroup, 40 us apart,
+    // re-fetched S for every tile: 16 GB per launch on the fabric counters.)  Pure speed: any placement gives the same result.
     const int n_walkers = ntiles / N;
-    const int n_my = ((n_walkers - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * N;
-    auto tile_of = [&](int it) { return ((int)blockIdx.x + (it / N) * (int)gridDim.x) * N + it % N; };
+    const int nx = ((gridDim.x & 7) == 0 && n_walkers >= 16) ? 8 : 1, per = (int)gridDim.x / nx;      // (few walkers: plain tile order)
+    const int xcd = (int)blockIdx.x % nx, jx = (int)blockIdx.x / nx;
+    const int stream_tiles = ((n_walkers - xcd + nx - 1) / nx) * N;              // tiles of this XCD's walkers
+    const int n_my = stream_tiles > jx ? (stream_tiles - jx + per - 1) / per : 0;
+    auto tile_of = [&](int it) {
+        const int t = it * per + jx;
+        return ((t / N) * nx + xcd) * N + t % N;
+    };
     auto a_ptr = [&](int c, int p, int pass) { return WP + ((((size_t)c * NPL + p) * nf16 + 2 * wave + pass) * 4 + lq) * 16 + lr; };
     auto stage = [&](int g) {                 // raw rows of chunk g of the stream -> R[g & 1]: wave w brings rows 8 w .. 8 w + 7 (5 x 1 KB)
         const int tile = tile_of(g / NCH), c = g % NCH;
@@ -192,7 +204,7 @@ __global__ void __launch_bounds__(512, 1) k_layer_i8(const double* __restrict__ 
         for (int u = 0; u < 5; ++u) {
             const int pc = 5 * wave + u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * pc),
-                                             (__attribute__((address_space(3))) void*)(dst + 64 * pc), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + 64 * pc), 16, 0, DS_I8_RAW_AUX);
         }
     };
     if (n_my <= 0) return;
