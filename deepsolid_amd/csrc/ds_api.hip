@@ -1385,8 +1385,8 @@ int check_arch(const ds_system_desc* d) {
     if (d->distance_type != 0 && d->distance_type != 1) return fail("Unrecognized distance function.");
     if (d->distance_type == 1 && d->envelope_type != 0) return fail("the 'tri' features support the isotropic envelope only");
     if (d->envelope_type < 0 || d->envelope_type > 2) return fail("unknown envelope_type");
-    if (d->n_up < 1) return fail("n_up must be >= 1");
-    if (d->n_dn < 0) return fail("n_dn must be >= 0");
+    if (d->n_up < 0 || d->n_dn < 0) return fail("n_up and n_dn must be >= 0");
+    if (d->n_up < 1) return fail("internal: n_up must be >= 1 here (ds_system_create swaps a spin-down-only cell)");
     if (d->n_layers < 1 || d->n_layers > DS_MAX_LAYERS) return fail("bad n_layers");
     if (d->n_det < 1 || d->n_det > DS_MAX_DETS) return fail("n_det must be in 1..%d", DS_MAX_DETS);
     if (d->n_sym < 3 || d->n_sym > DS_MAX_SYM) return fail("bad n_sym");
@@ -1435,6 +1435,15 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
                                  dev_desc.hidden_single, dev_desc.hidden_double, rs, rd))
             return rc;
     }
+    // only spin-down electrons: the reference drops the empty channel (network.py:113-117 filters `spins`), which leaves the network
+    // of the mirrored cell (n_dn, 0) with the same parameter tree -- run that
+    if (dev_desc.n_up == 0 && dev_desc.n_dn > 0) {
+        dev_desc.n_up = dev_desc.n_dn;
+        dev_desc.n_dn = 0;
+        dev_desc.klist_up = dev_desc.klist_dn;
+        dev_desc.klist_dn = nullptr;
+    }
+    if (dev_desc.n_up + dev_desc.n_dn < 1) return fail("n_up + n_dn must be >= 1");
     const ds_system_desc* desc = &dev_desc;
     if (int rc = check_arch(desc)) return rc;
     if (!desc->prim_atoms || !desc->klist_up || (desc->n_dn > 0 && !desc->klist_dn) || !desc->sim_atoms || !desc->sim_charges ||

@@ -74,6 +74,11 @@ class DeviceSystem:
         self.tables = tables
         prim = simulation_cell.original_cell
         self.nelec = tuple(int(n) for n in simulation_cell.nelec)
+        if self.nelec[0] == 0 and self.nelec[1] > 0:
+            # only spin-down electrons: the reference drops the empty channel (network.py:113-117), which leaves the network of the
+            # mirrored cell (n_dn, 0) with the same parameter tree; the library does the same swap for a C caller
+            self.nelec = (self.nelec[1], 0)
+            klist = (klist[1], klist[0])
         self.n = sum(self.nelec)
         self.n_det = int(net_kw['determinants'])
         self.hidden_dims = tuple(tuple(int(v) for v in h) for h in net_kw['hidden_dims'])

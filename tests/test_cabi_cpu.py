@@ -156,6 +156,7 @@ def test_shape_limits_are_rejected_at_create():
     assert 'residual' in err(hidden_single=[4, 256, 256])            # n_atoms_prim = 1, 'nu': 4 input features
     assert 'residual' in err(hidden_double=[4, 32, 32])
     assert 'n_det' in err(n_det=65)
-    assert 'n_up' in err(n_up=0)
+    assert 'null array' in err(n_up=0, n_dn=4)                     # a spin-down-only cell runs as its mirror image (round 5)
+    assert 'n_up' in err(n_up=0, n_dn=0)
     assert 'n_dn' in err(n_dn=-1)
     assert 'tri' in err(distance_type=1, envelope_type=2)
