@@ -39,7 +39,7 @@ def tt(a):
 
 @functools.lru_cache(maxsize=None)
 def _float32_budget_walker(name, b):
-    """(ref, loss) of fixture walker b: the committed numbers of tests/golden/f32_budget.npz where they exist (made by
+    """(ref, loss) of fixture walker b from the oracle: the committed numbers of tests/golden/f32_budget.npz where they exist (made by
     tools/f32_budget_fixture.py with exactly the computation below: the 96-electron walkers cost 7 s of CPU each), else computed."""
     path = os.path.join(GOLDEN, 'f32_budget.npz')
     if os.path.exists(path):
@@ -47,6 +47,18 @@ def _float32_budget_walker(name, b):
         if f'{name}_ref' in fxb and b < len(fxb[f'{name}_ref']):
             return complex(fxb[f'{name}_ref'][b]), float(fxb[f'{name}_loss'][b])
     return compute_float32_budget_walker(name, b)
+
+
+def float32_reference_run(name, nb):
+    """The REFERENCE'S OWN float32 run (tests/golden/f32_reference.npz, tools/make_f32_reference.py: its hamiltonian.py over its
+    network.py executed in float32 / complex64, as JAX runs it by default, and in float64 at the same float32-rounded walkers):
+    -> (ref64, loss) with ref64[b] the reference's float64 E_kin at the rounded walker and loss[b] =
+    |E_kin(reference, float32) - ref64| / max(1, |ref64|).  Diamond: 2.0e-5, 3.5e-4, 3.6e-3, 2.1e-4 -- the reference's 3N
+    forward-over-reverse sweeps lose MORE digits in float32 than the forward-Laplacian chain (oracle: 1.4e-5 ... 6.2e-4)."""
+    fxr = np.load(os.path.join(GOLDEN, 'f32_reference.npz'))
+    ref = [complex(v) for v in fxr[f'{name}_ke_f64_at_x32'][:nb]]
+    loss = [float(abs(complex(fxr[f'{name}_ke_f32'][b]) - ref[b]) / max(1.0, abs(ref[b]))) for b in range(nb)]
+    return tuple(ref), tuple(loss)
 
 
 def compute_float32_budget_walker(name, b):
@@ -62,9 +74,10 @@ def compute_float32_budget_walker(name, b):
 
 
 def float32_budget(name, nb):
-    """What a straight float32 evaluation of the reference algorithm loses on the first `nb` fixture walkers of a case:
+    """What a straight float32 evaluation of the reference ALGORITHM loses on the first `nb` fixture walkers of a case:
     -> (ref, loss) with ref[b] the float64 forward-Laplacian oracle E_kin at the float32-ROUNDED walker and loss[b] the
     relative error |E_kin(f32 oracle) - ref| / max(1, |ref|) of the same restatement run in float32 on the CPU.
+    (What the reference's own code loses in float32 is in `float32_reference_run`: more, at the worst walker 6 x more.)
     The loss is a property of the walker (conditioning), not of an implementation: on diamond it ranges from 1e-5 to 6e-4
     over the four fixture walkers and walker 1's moves between 1e-4 and 5e-4 with the host's BLAS summation order
     (tools/f32_budget.py), so float32 tests bound the HIP chain by `float32_tolerance`, not by one number per case."""

@@ -1,5 +1,7 @@
 """Pins the CPU oracle (and the PySCF-free system builder) against vectors
 produced by executing the reference's own code (tools/make_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,7 +13,7 @@ from oracle import network as onet
 from oracle import qmc as oqmc
 from oracle.testing import CASES
 
-from common import load_case, oracle_net, tt
+from common import GOLDEN, load_case, oracle_net, tt
 
 ALL = list(CASES)
 SMALL = [c for c in ALL if c not in ('graphene', 'diamond')]
@@ -305,3 +307,25 @@ def test_other_samplers_match_reference(name):
     np.testing.assert_allclose(xi.numpy(), fx['imp_x_new'], atol=1e-10)
     np.testing.assert_allclose(lpi.numpy(), fx['imp_lp_new'], atol=1e-8)
     assert float(na) == float(fx['imp_num_accepts'])
+
+
+@pytest.mark.parametrize('name', ['lih', 'bcc_li'])
+def test_float32_reference_fixture_is_consistent(name):
+    """tests/golden/f32_reference.npz (tools/make_f32_reference.py: the reference's own hamiltonian.py in float32 and, at the same
+    float32-rounded walkers, in float64): the float64 leg must agree with the oracle at the rounded walker to 1e-9 (the same bar
+    as every ke_ref fixture), the rounded walkers must be the fixture's, and the float32 leg must be a float32-sized distance away
+    (between 1e-8 and 1e-2 relative: neither a float64 run in disguise nor garbage)."""
+    from oracle import forward_laplacian as ofl
+    from oracle import network as onet
+    fx, cell, klist, net_kw, params = load_case(name)
+    fxr = np.load(os.path.join(GOLDEN, 'f32_reference.npz'))
+    nb = len(fxr[name + '_ke_f32'])
+    np.testing.assert_array_equal(fxr[name + '_x32'], fx['x'][:nb].astype(np.float32))
+    assert fxr[name + '_ke_f32'].dtype == np.complex64
+    p = onet.params_to_torch(params)
+    for b in range(nb):
+        r64 = complex(fxr[name + '_ke_f64_at_x32'][b])
+        o = complex(ofl.stages(p, torch.as_tensor(fxr[name + '_x32'][b].astype(np.float64)), klist, cell, net_kw)['ke'])
+        assert abs(o - r64) < 1e-9 * max(1.0, abs(r64)), (b, o, r64)
+        rel = abs(complex(fxr[name + '_ke_f32'][b]) - r64) / max(1.0, abs(r64))
+        assert 1e-8 < rel < 1e-2, (b, rel)

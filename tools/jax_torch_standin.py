@@ -30,6 +30,21 @@ import torch
 import torch.func as tf
 
 _TORCH_MODE = [False]
+# Working precision of the torch legs: float64 / complex128 (every fixture of rounds 2-4), or float32 / complex64 for
+# tools/make_f32_reference.py -- the reference's own hamiltonian.py run the way JAX runs it by default, in single precision.
+WORK = [torch.float64, torch.complex128]
+
+
+@contextlib.contextmanager
+def working_dtype(real):
+    old = list(WORK)
+    WORK[0] = real
+    WORK[1] = torch.complex64 if real == torch.float32 else torch.complex128
+    try:
+        yield
+    finally:
+        WORK[0], WORK[1] = old
+
 
 
 @contextlib.contextmanager
@@ -56,7 +71,12 @@ def _t(o):
         return o
     if isinstance(o, (list, tuple)) and _has_tensor(o):
         return torch.stack([_t(v) for v in o])
-    return torch.as_tensor(np.asarray(o))
+    t = torch.as_tensor(np.asarray(o))
+    if t.is_floating_point() and t.dtype != WORK[0]:
+        t = t.to(WORK[0])
+    elif t.is_complex() and t.dtype != WORK[1]:
+        t = t.to(WORK[1])
+    return t
 
 
 def to_numpy(t):
@@ -194,9 +214,9 @@ def _make_jnp():
     def ctor(name, timpl):
         np_impl = getattr(np, name)
         setattr(jnp, name, lambda *a, **k: (timpl(*a, **k) if _TORCH_MODE[0] else np_impl(*a, **k)))
-    ctor('eye', lambda n: torch.eye(n, dtype=torch.float64))
-    ctor('ones', lambda shape: torch.ones(tuple(shape) if not isinstance(shape, int) else (shape,), dtype=torch.float64))
-    ctor('zeros', lambda shape: torch.zeros(tuple(shape) if not isinstance(shape, int) else (shape,), dtype=torch.float64))
+    ctor('eye', lambda n: torch.eye(n, dtype=WORK[0]))
+    ctor('ones', lambda shape: torch.ones(tuple(shape) if not isinstance(shape, int) else (shape,), dtype=WORK[0]))
+    ctor('zeros', lambda shape: torch.zeros(tuple(shape) if not isinstance(shape, int) else (shape,), dtype=WORK[0]))
 
     linalg = types.ModuleType('jax.numpy.linalg')
     for name in dir(np.linalg):
@@ -224,9 +244,9 @@ def _np_median(t):
 
 def _promote_all(ts):
     if any(t.is_complex() for t in ts):
-        return [t.to(torch.complex128) for t in ts]
+        return [t.to(WORK[1]) for t in ts]
     if any(t.is_floating_point() for t in ts):
-        return [t.to(torch.float64) if not t.is_floating_point() else t for t in ts]
+        return [t.to(WORK[0]) if not t.is_floating_point() else t for t in ts]
     return ts
 
 
