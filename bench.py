@@ -82,6 +82,8 @@ def gemm_instance(n_elec, dtype, epi):
     st = (3 * n_elec + 2 + 15) // 16
     nb = 4 if st <= 5 else (2 if st <= 10 else (2 if dtype == torch.float32 else 1))
     tname = 'double' if dtype == torch.float64 else 'float'
+    if epi == 5 and st > 10 and dtype == torch.float32 and not os.environ.get('DS_NO_LDSB'):
+        return f'k_jet_gemm_lb<float,{st},5,4>', 1, st            # orbital head of the wide float32 cells: jet rows staged in LDS (ds_ldsb.h)
     return f'k_jet_gemm<{tname},{nb},{st},{epi}>', nb, st
 
 

@@ -103,6 +103,7 @@ struct ds_system {
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
+    bool use_ldsb = true;             // DS_NO_LDSB unset: float32 cells with more than 10 slot tiles run the orbital head with LDS-staged jet rows (ds_ldsb.h)
     bool use_i8 = true;               // DS_NO_I8 unset: dense hidden layers of the 5-slot-tile float64 cells run their per-electron contraction as an int8 split (ds_i8.h)
     void* i8_wp = nullptr;            // digit planes of that layer's weights + (behind them) the 256 column scales, refilled at every call
     int n_cu = 256;                   // compute units of the device (grid of the persistent int8 layer kernel)
@@ -609,7 +610,10 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             } else {
                 dim3 wb; unsigned wz;
                 gemm_geom(OC, 4, &wb, &wz, 6);
-                if (!(wide && to->gemm_wide(5, s->wide_all, dim3(ns * wz, (unsigned)Bc, 1), wb, st, ga)))
+                if (wide && to->gemm_wide(5, s->wide_all, dim3(ns * wz, (unsigned)Bc, 1), wb, st, ga)) {
+                } else if (to->orbital_lb && s->use_ldsb && OC % 64 == 0 && ga.K % 16 == 0)    // float32 wide cells: jet rows staged in LDS (ds_ldsb.h)
+                    to->orbital_lb(dim3(ns * (unsigned)(OC / 64), (unsigned)Bc, 1), st, ga);
+                else
                     to->gemm(5, dim3(ns * gz, (unsigned)Bc, 1), block, st, ga);
             }
         }
@@ -1504,6 +1508,7 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
     s->use_i8 = getenv("DS_NO_I8") == nullptr;
+    s->use_ldsb = getenv("DS_NO_LDSB") == nullptr;
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     s->use_wide = getenv("DS_NO_WIDE") == nullptr;
     s->wide_all = getenv("DS_WIDE_ALL") != nullptr;

@@ -245,6 +245,71 @@ __device__ __forceinline__ void layer_epilogue_sadd(typename Acc4<T>::type (&acc
     }
 }
 
+// Fused orbital-head epilogue (network.py:543-557) on a wave's accumulator tile: complex phi from the packed (Re, Im) columns, M = phi * q
+// (envelope x Bloch phase 5-jet of the tile's electron) with the product rule on the jets, stored into MOUT (slot-tile major).
+template <typename T, int NB, int ST>
+__device__ __forceinline__ void orbital_epilogue(typename Acc4<T>::type (&acc)[NB][ST], const OrbEpi<T>& oe, int tile, int w, int n0, int lane,
+                                                 const T* __restrict__ Sb, int Nout, int P) {
+    const int lr = lane & 15, lq = lane >> 4;
+    const int i = oe.i0 + tile, so = 2 + 3 * i, base = lane & 48;
+    T* Mw = oe.MOUT + (size_t)w * oe.mout_stride + oe.mout_off;
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) {
+            const int p = 8 * (n0 / 16 + a) + lq + 4 * ab;
+            const bool valid = p < oe.nparam;
+            const T* q = oe.Q + ((size_t)(w * oe.N + i) * oe.nparam_max + (valid ? p : 0)) * 10;
+            const Cx<T> qv(q[0], q[1]), qg0(q[2], q[3]), qg1(q[4], q[5]), qg2(q[6], q[7]), ql(q[8], q[9]);
+            Cx<T> phi[ST];
+#pragma unroll
+            for (int s = 0; s < ST; ++s) phi[s] = Cx<T>(acc[a][s][2 * ab], acc[a][s][2 * ab + 1]);
+            if (Sb) {   // use_last_layer: the orbital input has spin-mean rows too (network.py:535) -> shared term
+                const T* Sr = Sb + (size_t)w * Nout * P + (size_t)(n0 + 16 * a + acc_row<T>(lane, 2 * ab)) * P + lr;
+                const T* Si = Sb + (size_t)w * Nout * P + (size_t)(n0 + 16 * a + acc_row<T>(lane, 2 * ab + 1)) * P + lr;
+#pragma unroll
+                for (int s = 0; s < ST; ++s) { phi[s].re += Sr[16 * s]; phi[s].im += Si[16 * s]; }
+            }
+            if (oe.bias && valid && lr == 0) { phi[0].re += oe.bias[p]; phi[0].im += oe.bias[oe.nparam + p]; }
+            const Cx<T> f0(row16_bcast<0>(phi[0].re), row16_bcast<0>(phi[0].im));
+            const Cx<T> fL(row16_bcast<1>(phi[0].re), row16_bcast<1>(phi[0].im));
+            Cx<T> fo[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // slot sl = so + c of this row: pick its slot tile first (st is workgroup-uniform), then ONE cross-lane read
+                const int sl = so + c, st = sl >> 4, src = base | (sl & 15);
+                T re = phi[0].re, im = phi[0].im;
+#pragma unroll
+                for (int s = 1; s < ST; ++s)
+                    if (s == st) { re = phi[s].re; im = phi[s].im; }
+                fo[c] = Cx<T>(__shfl(re, src), __shfl(im, src));
+            }
+            const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
+            if (valid) {
+                const int kdet = p / oe.norb, m = p % oe.norb;
+                // MOUT is slot-tile major: [det][slot tile][elec][orb][re,im][16]
+                T* mo = Mw + (size_t)kdet * oe.n * oe.n * 2 * P + (((size_t)(oe.row0 + tile) * oe.n + m) * 2) * 16 + lr;
+                const size_t tstride = (size_t)oe.n * oe.n * 2 * 16;
+                // the electron's own three coordinate slots live in slot tile(s) st0 (.. st1), workgroup-uniform: only those
+                // tiles pay for the lane selects; the Laplacian slot is lane 1 of tile 0
+                const Cx<T> t0 = f0 * qg0, t1 = f0 * qg1, t2 = f0 * qg2;
+                const int st0 = so >> 4, st1 = (so + 2) >> 4;
+#pragma unroll
+                for (int s = 0; s < ST; ++s) {
+                    T vr = phi[s].re * qv.re - phi[s].im * qv.im, vi = phi[s].re * qv.im + phi[s].im * qv.re;
+                    if (s == st0 || s == st1) {
+                        const int dsl = 16 * s + lr - so;
+                        vr += dsl == 0 ? t0.re : (dsl == 1 ? t1.re : (dsl == 2 ? t2.re : T(0)));
+                        vi += dsl == 0 ? t0.im : (dsl == 1 ? t1.im : (dsl == 2 ? t2.im : T(0)));
+                    }
+                    if (s == 0) { vr = lr == 1 ? lap.re : vr; vi = lr == 1 ? lap.im : vi; }
+                    __builtin_nontemporal_store(vr, &mo[s * tstride]);          // MOUT is read again only by the determinant kernels
+                    __builtin_nontemporal_store(vi, &mo[s * tstride + 16]);
+                }
+            }
+        }
+}
+
 // One workgroup = one "tile" (the P jet slots of one electron, or of the spin means) x up to 1024/NB
 // output features (grid.z walks further column blocks); every wave owns 16*NB features.  Tiles 0..n_tiles-1 use (X, W, K);
 // the optional extra tile (blockIdx.x == n_tiles) uses (X2, W2, K2): the shared spin-mean term.
@@ -441,63 +506,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                     Zp[(size_t)n * P + 16 * s + lr] = acc[a][s][r] + ((EPI == 7 || (EPI == 6 && s == 0 && lr == 0)) ? bn : T(0));
             }
     } else if (EPI == 5) {
-        const int i = oe.i0 + tile, so = 2 + 3 * i, base = lane & 48;
-        T* Mw = oe.MOUT + (size_t)w * oe.mout_stride + oe.mout_off;
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-            for (int ab = 0; ab < 2; ++ab) {
-                const int p = 8 * (n0 / 16 + a) + lq + 4 * ab;
-                const bool valid = p < oe.nparam;
-                const T* q = oe.Q + ((size_t)(w * oe.N + i) * oe.nparam_max + (valid ? p : 0)) * 10;
-                const Cx<T> qv(q[0], q[1]), qg0(q[2], q[3]), qg1(q[4], q[5]), qg2(q[6], q[7]), ql(q[8], q[9]);
-                Cx<T> phi[ST];
-#pragma unroll
-                for (int s = 0; s < ST; ++s) phi[s] = Cx<T>(acc[a][s][2 * ab], acc[a][s][2 * ab + 1]);
-                if (Sb) {   // use_last_layer: the orbital input has spin-mean rows too (network.py:535) -> shared term
-                    const T* Sr = Sb + (size_t)w * Nout * P + (size_t)(n0 + 16 * a + acc_row<T>(lane, 2 * ab)) * P + lr;
-                    const T* Si = Sb + (size_t)w * Nout * P + (size_t)(n0 + 16 * a + acc_row<T>(lane, 2 * ab + 1)) * P + lr;
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) { phi[s].re += Sr[16 * s]; phi[s].im += Si[16 * s]; }
-                }
-                if (oe.bias && valid && lr == 0) { phi[0].re += oe.bias[p]; phi[0].im += oe.bias[oe.nparam + p]; }
-                const Cx<T> f0(row16_bcast<0>(phi[0].re), row16_bcast<0>(phi[0].im));
-                const Cx<T> fL(row16_bcast<1>(phi[0].re), row16_bcast<1>(phi[0].im));
-                Cx<T> fo[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    // slot sl = so + c of this row: pick its slot tile first (st is workgroup-uniform), then ONE cross-lane read
-                    const int sl = so + c, st = sl >> 4, src = base | (sl & 15);
-                    T re = phi[0].re, im = phi[0].im;
-#pragma unroll
-                    for (int s = 1; s < ST; ++s)
-                        if (s == st) { re = phi[s].re; im = phi[s].im; }
-                    fo[c] = Cx<T>(__shfl(re, src), __shfl(im, src));
-                }
-                const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
-                if (valid) {
-                    const int kdet = p / oe.norb, m = p % oe.norb;
-                    // MOUT is slot-tile major: [det][slot tile][elec][orb][re,im][16]
-                    T* mo = Mw + (size_t)kdet * oe.n * oe.n * 2 * P + (((size_t)(oe.row0 + tile) * oe.n + m) * 2) * 16 + lr;
-                    const size_t tstride = (size_t)oe.n * oe.n * 2 * 16;
-                    // the electron's own three coordinate slots live in slot tile(s) st0 (.. st1), workgroup-uniform: only those
-                    // tiles pay for the lane selects; the Laplacian slot is lane 1 of tile 0
-                    const Cx<T> t0 = f0 * qg0, t1 = f0 * qg1, t2 = f0 * qg2;
-                    const int st0 = so >> 4, st1 = (so + 2) >> 4;
-#pragma unroll
-                    for (int s = 0; s < ST; ++s) {
-                        T vr = phi[s].re * qv.re - phi[s].im * qv.im, vi = phi[s].re * qv.im + phi[s].im * qv.re;
-                        if (s == st0 || s == st1) {
-                            const int dsl = 16 * s + lr - so;
-                            vr += dsl == 0 ? t0.re : (dsl == 1 ? t1.re : (dsl == 2 ? t2.re : T(0)));
-                            vi += dsl == 0 ? t0.im : (dsl == 1 ? t1.im : (dsl == 2 ? t2.im : T(0)));
-                        }
-                        if (s == 0) { vr = lr == 1 ? lap.re : vr; vi = lr == 1 ? lap.im : vi; }
-                        __builtin_nontemporal_store(vr, &mo[s * tstride]);          // MOUT is read again only by the determinant kernels
-                        __builtin_nontemporal_store(vi, &mo[s * tstride + 16]);
-                    }
-                }
-            }
+        orbital_epilogue<T, NB, ST>(acc, oe, tile, w, n0, lane, Sb, Nout, P);
     } else if (EPI == 8) {
         // value chain (slot tiles = 80 walkers of group w): M = (phi + S + bias) * q straight from the accumulators into MOUT
         // [group][spin][det][elec][orb][re,im][PV] -- the arithmetic of k_orbital_epilogue_val without the trip through PHI

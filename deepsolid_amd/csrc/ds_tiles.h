@@ -6,6 +6,7 @@
 #pragma once
 #include "ds_gemm.h"
 #include "ds_wide.h"
+#include "ds_ldsb.h"
 
 namespace ds {
 
@@ -35,6 +36,9 @@ template <typename T> struct TileOps {
     // float32 only layer 0 -- unless force is set (DS_WIDE_ALL=1: tests, A/B runs).
     bool (*gemm_wide)(int epi, bool force, dim3 grid, dim3 block, hipStream_t st, const GemmArgs<T>& a);
     bool (*layer1_lr_wide)(int nc, bool res, bool force, dim3 grid, dim3 block, hipStream_t st, const LrArgs<T>& a);
+    // float32, ST > 10 (ds_ldsb.h): k_jet_gemm_lb<float, ST, 5, 4>, the orbital head with four 16-feature waves per workgroup and the
+    // tile's jet rows staged in LDS; grid = (n_tiles x Nout / 64, walkers), block 256.  Null otherwise.
+    void (*orbital_lb)(dim3 grid, hipStream_t st, const GemmArgs<T>& a);
 };
 
 constexpr int DS_MAX_TILES = 25;

@@ -97,9 +97,15 @@ template <typename T, int NB, int ST> struct TileImpl {
         }
         return false;
     }
+    static void orbital_lb(dim3 grid, hipStream_t st, const GemmArgs<T>& a) {
+        if constexpr (ST > 10 && sizeof(T) == 4)
+            hipLaunchKernelGGL((k_jet_gemm_lb<T, ST, 5, 4>), grid, dim3(256), ldsb_bytes<T>(a.P), st, a.X, a.xws, a.xts, a.W, a.K, a.n_tiles, a.Z, a.zws,
+                               a.zts, a.Nout, a.P, a.Sb, a.oe);
+    }
     static const TileOps<T>* ops() {
         static const TileOps<T> o = {NB, ST, &gemm, (ST <= 5 ? &gemm_orb3 : nullptr), &shared_term, &layer1_lr, (ST <= 5 ? &layer0_stats : nullptr),
-                                      (ST > 10 ? &gemm_wide : nullptr), (ST > 10 ? &layer1_lr_wide : nullptr)};
+                                      (ST > 10 ? &gemm_wide : nullptr), (ST > 10 ? &layer1_lr_wide : nullptr),
+                                      ((ST > 10 && sizeof(T) == 4) ? &orbital_lb : nullptr)};
         return &o;
     }
 };

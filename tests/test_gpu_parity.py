@@ -530,6 +530,31 @@ def test_wide_slot_range_kernels_vs_single_pass_kernels(name, dtype, monkeypatch
             assert abs(v - ref[0]) < float32_tolerance(loss, 0) * max(1.0, abs(ref[0])), (v, ref[0])
 
 
+def test_lds_staged_orbital_head_vs_register_streaming_kernel(monkeypatch):
+    """float32 cells with more than 10 jet-slot tiles run the orbital head as k_jet_gemm_lb (csrc/ds_ldsb.h: four 16-feature waves
+    share the tile's jet rows through LDS); DS_NO_LDSB=1 (read at system creation) keeps k_jet_gemm.  Same MFMA products in the same
+    k order on both paths, so E_kin of the diamond walker agrees far inside the float32 tolerance of the walker -- and each run
+    holds that tolerance against the float64 oracle."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case('diamond')
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    x = torch.as_tensor(fx['x'][:2], dtype=torch.float32, device='cuda')
+    out = []
+    for off in (False, True):
+        monkeypatch.delenv('DS_NO_LDSB', raising=False)
+        if off:
+            monkeypatch.setenv('DS_NO_LDSB', '1')
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float32)
+        out.append(torch.view_as_complex(sysd.local_energy(dp, x)[0].double()).cpu().numpy())
+    a, b = out
+    ref, loss = float32_budget('diamond', 2)
+    for i in range(2):
+        tol = float32_tolerance(loss, i) * max(1.0, abs(ref[i]))
+        assert abs(a[i] - b[i]) < 0.05 * tol, (a[i], b[i], tol)
+        assert abs(a[i] - ref[i]) < tol and abs(b[i] - ref[i]) < tol, (a[i], b[i], ref[i])
+
+
 @pytest.mark.parametrize('S,dtype', [((3, 3, 2), torch.float64), ((4, 3, 2), torch.float64), ((4, 3, 2), torch.float32)])
 def test_intermediate_electron_counts_vs_oracle(S, dtype):
     """Electron counts between the BASELINE sizes that had no kernel instances before round 4: bcc-Li 3x3x2 (54 e-, 11 jet-slot
