@@ -103,6 +103,7 @@ struct ds_system {
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
+    bool use_pair_fuse = true;        // DS_NO_PAIR_FUSE unset: a log-psi forward runs all pair layers in one launch (k_pair_stream_val, ds_value.h)
     bool use_ldsb = true;             // DS_NO_LDSB unset: float32 cells with more than 10 slot tiles run the orbital head with LDS-staged jet rows (ds_ldsb.h)
     bool use_i8 = true;               // DS_NO_I8 unset: dense hidden layers of the 5-slot-tile float64 cells run their per-electron contraction as an int8 split (ds_i8.h)
     void* i8_wp = nullptr;            // digit planes of that layer's weights + (behind them) the 256 column scales, refilled at every call
@@ -758,6 +759,22 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
                        blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), vb.Gl[0], vb.MEAN0, vb.H2l[0], Q);
     const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
     const bool fuse_means = S.n_up >= 8 && (S.n_dn >= 8 || S.n_dn == 0);
+    // log psi only: every pair layer in one launch, activations in registers (k_pair_stream_val).  Needs equal pair widths with a
+    // kernel instance, no residual on the first pair layer (its input has another width anyway) and the segment sums as the only
+    // consumer of the pair stream.  The sums of layer l go to PARTM (l = 0) and into the second H2 buffer, which this path leaves
+    // unused (a PARTM block is 3/16 of an H2 buffer).
+    bool fuse_pairs = fuse_means && !vb.MINV && s->use_pair_fuse && S.n_double >= 1 && S.n_double <= ds::PS_MAX_LAYERS && !s->res2[0] &&
+                      S.h2[0] % 4 == 0 && (S.h2[1] == 16 || S.h2[1] == 32) && (size_t)(S.n_double - 1) * L.PARTM <= L.H2;
+    for (int l = 1; l < S.n_double; ++l) fuse_pairs = fuse_pairs && S.h2[l + 1] == S.h2[1];
+    auto pm_of = [&](int l) -> T* { return (!fuse_pairs || l == 0) ? vb.PARTM : vb.H2l[1] + (size_t)(l - 1) * L.PARTM * ng; };
+    if (fuse_pairs) {
+        ds::PairStreamArgs<T> pa{};
+        pa.H0 = vb.H2l[0]; pa.Kin0 = S.h2[0]; pa.nl = S.n_double;
+        for (int l = 0; l < S.n_double; ++l) { pa.W[l] = blk(s->i_w2[l]); pa.b[l] = blk(s->i_b2[l]); pa.res[l] = s->res2[l] ? 1 : 0; pa.PM[l] = pm_of(l); }
+        dim3 grid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
+        if (S.h2[1] == 32) hipLaunchKernelGGL((ds::k_pair_stream_val<T, 2>), grid, dim3(256), 0, st, S, pa);
+        else hipLaunchKernelGGL((ds::k_pair_stream_val<T, 1>), grid, dim3(256), 0, st, S, pa);
+    }
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
         T* Gin = vb.Gl[l]; T* Gout = vb.Gl[l + 1];
@@ -766,10 +783,10 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         // partner means of the pair stream -> rows [Kh, Kh + nch*K2): layer 0 from H2 itself; later layers from the segment sums
         // the previous pair layer left behind (no second pass over H2) when every spin has >= 8 electrons
         if (l > 0 && l <= S.n_double && fuse_means)
-            hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng, (unsigned)(S.nch * K2 / m2_rc(K2))), dim3(256), (size_t)m2_rc(K2) * PV * sizeof(T), st, S, vb.PARTM, K2, Gin, Kh, m2_rc(K2));
+            hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng, (unsigned)(S.nch * K2 / m2_rc(K2))), dim3(256), (size_t)m2_rc(K2) * PV * sizeof(T), st, S, pm_of(l - 1), K2, Gin, Kh, m2_rc(K2));
         else
             hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, Hin, K2, Gin, Kh);
-        if (l < S.n_double) {
+        if (l < S.n_double && !fuse_pairs) {
             const int K2o = S.h2[l + 1];
             if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
             dim3 grid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
@@ -826,7 +843,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
     T* Gl = vb.Gl[S.n_layers];
     const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
     if (s->use_last) {
-        if (fuse_means) hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng, (unsigned)(S.nch * K2l / m2_rc(K2l))), dim3(256), (size_t)m2_rc(K2l) * PV * sizeof(T), st, S, vb.PARTM, K2l, Gl, Kl, m2_rc(K2l));
+        if (fuse_means) hipLaunchKernelGGL((ds::k_m2_combine_val<T>), dim3(S.N, (unsigned)ng, (unsigned)(S.nch * K2l / m2_rc(K2l))), dim3(256), (size_t)m2_rc(K2l) * PV * sizeof(T), st, S, pm_of(S.n_double - 1), K2l, Gl, Kl, m2_rc(K2l));
         else hipLaunchKernelGGL((ds::k_m2_expand_val<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, S, vb.H2l[S.n_double], K2l, Gl, Kl);
     }
     for (int sp = 0; sp < S.nch; ++sp) {
@@ -1509,6 +1526,7 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
     s->use_i8 = getenv("DS_NO_I8") == nullptr;
     s->use_ldsb = getenv("DS_NO_LDSB") == nullptr;
+    s->use_pair_fuse = getenv("DS_NO_PAIR_FUSE") == nullptr;
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     s->use_wide = getenv("DS_NO_WIDE") == nullptr;
     s->wide_all = getenv("DS_WIDE_ALL") != nullptr;

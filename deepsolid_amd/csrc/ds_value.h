@@ -180,6 +180,181 @@ __global__ void __launch_bounds__(256) k_m2_expand_val(SysDev<T> S, const T* __r
     }
 }
 
+// The whole two-electron stream of a log-psi forward in ONE launch (network.py:525-528 for every pair layer): the pair stream never
+// reads the one-electron stream, so a wave that owns 16 pairs x 5 walkers can run layer after layer on them without the
+// activations leaving its registers.  The accumulator layout of the 16x16x4 MFMA (rows = output features, columns = pairs) IS the
+// layout of its B operand (k = features), so layer l's output feeds layer l + 1's product directly: step (a, r) contracts the four
+// features 16 a + acc_row(lane, r) with the matching weight rows -- in float64 the same k order as k_two_layer, so the
+// activations are bit-identical to the layer-by-layer kernels.  What leaves the kernel is only what the one-electron layers need:
+// per layer the running sums of the tile's (electron, partner spin) segments, PM[l] laid out exactly as k_two_layer's PARTM
+// ([5-walker block][tile][slot][feature][column]; k_m2_combine_val reads it).  The sums over the 16 pairs of a tile are taken
+// on the matrix pipe: a layer's outputs are staged [column][feature][pair] through LDS, read back in the A-operand layout and
+// multiplied with the indicator matrix [pair < end of segment q] (exact products; details at `ind` below) in place of 40
+// sixteen-lane DPP prefix sums of ~16 instructions each; with no per-value control flow left the tanh chains of a column are one
+// basic block (their constants are materialised once -- in k_two_layer every value re-materialises them: 75 instead of 45 VALU
+// instructions per tanh -- and the chains interleave).
+// The kernel is bound by the FP64 datapath, which the float64 MFMA SHARES with the float64 VALU on gfx950 (a 16x16x4 product
+// occupies it for 64 cycles: SQ_VALU_MFMA_BUSY_CYCLES 34 % + SQ_ACTIVE_INST_VALU 53 % of the kernel's cycles, and removing the
+// tanh, the sums or the stores from the kernel shortens it by exactly their own cycles -- nothing overlaps, EXPERIMENTS.md
+// round 5): per tile 80 tanh x 45 instructions x 4 cycles = 14.4 k cycles, 100 product MFMAs = 6.4 k, 20 segment-sum products.
+// Replaces k_two_layer<.., VAL> x n_double and the H2 round trips between them in the Metropolis forward: bcc-Li 4096 walkers,
+// 0.372 + 0.239 ms -> 0.401 ms.  The gradient pass (activations kept) still runs the layer-by-layer kernels.
+// grid ((NP / 16 + 3) / 4, 5-walker blocks), block 256 (a wave per pair tile; no workgroup barrier).
+constexpr int PS_MAX_LAYERS = 8;
+template <typename T> struct PairStreamArgs {
+    const T* H0; int Kin0, nl;                                   // layer-0 input [block][Kin0][5][NP] (k_features_val), number of layers
+    const T* W[PS_MAX_LAYERS]; const T* b[PS_MAX_LAYERS]; int res[PS_MAX_LAYERS];   // res[0] must be 0
+    T* PM[PS_MAX_LAYERS];
+};
+template <typename T, int NT2>
+__global__ void __launch_bounds__(256, 2) k_pair_stream_val(SysDev<T> S, PairStreamArgs<T> A) {
+    typedef typename Acc4<T>::type acc_t;
+    constexpr int Kout = 16 * NT2, LD = sizeof(T) == 8 ? 18 : 20;     // LD: conflict-free A-operand reads (rows 16 apart in lanes)
+    constexpr int PMN = PM_SLOTS * Kout * 5;                     // segment sums of a tile: [slot][feature][column]
+    // per wave: 80 staging rows [column][feature] x 16 pairs (one 16-feature half of a layer's output), the tile's sums, and a
+    // dump area of a slot's extent (+ one element per lane) for the lanes that hold no slot
+    constexpr int WLDS = 80 * LD + PMN + Kout * 5 + 64;
+    __shared__ T ps_lds[4 * WLDS];
+    const int w = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pt = blockIdx.x * 4 + wave, NP = S.NP, N = S.N;
+    if (pt * 16 >= NP) return;
+    const int lr = lane & 15, lq = lane >> 4, p0 = pt * 16;
+    T* stage = ps_lds + wave * WLDS;
+    T* pml = stage + 80 * LD;
+    // ends (exclusive, relative to p0) of the first two (electron, partner spin) segments that meet this tile; the third runs to the end
+    auto next_end = [&](int p) { const int e = p / N, j = p - e * N; return (S.nch > 1 && j < S.n_up) ? e * N + S.n_up : (e + 1) * N; };
+    const int b1 = next_end(p0), b2 = next_end(b1);
+    const int e1 = b1 - p0 < 16 ? b1 - p0 : 16, e2 = b2 - p0 < 16 ? b2 - p0 : 16;
+    // Segment sums of a 16-feature x 16-pair tile V on the matrix pipe: PM[feature][slot q] = sum_pair V[feature][pair] * [pair < end_q].
+    // float64: v_mfma_f64_4x4x4_4b (four 4x4x4 blocks = the four groups of four features; 16 cycles against the 64 of the
+    // 16x16x4 form, whose 16 output columns would hold 3 slots -- the float64 MFMA runs on the same FP64 datapath as the tanh
+    // polynomials, so its cycles are not free): a = V[feature lane & 15][pair 4 s + (lane >> 4)] (the same LDS read as a 16x16x4 A
+    // operand), b = ind[pair 4 s + (lane >> 4)][slot lane & 3], d = PM[feature 4 ((lane >> 2) & 3) + (lane >> 4)][slot lane & 3]:
+    // one value per lane (tools/probes/mfma44_layout.hip).  float32: the 16x16x4 form, slot = column lane & 15.
+    constexpr bool M44 = sizeof(T) == 8;
+    const int slot = M44 ? (lane & 3) : lr;
+    T ind[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int pr = 4 * s4 + lq, lim = slot == 0 ? e1 : (slot == 1 ? e2 : 16);
+        ind[s4] = (slot < PM_SLOTS && p0 + pr < N * N && pr < lim) ? T(1) : T(0);
+    }
+    // where this lane's sums go in pml: its slot, or (lanes without one) the dump area behind the sums, one element apart per lane
+    T* pm_dst = pml + (slot < PM_SLOTS ? slot * Kout * 5 : PMN + lane);
+    const int f44 = 4 * ((lane >> 2) & 3) + lq;                  // float64: the feature (within the half) of this lane's sum
+    const T rs2 = T(0.70710678118654752440);
+    // D: the layer's input / output, all Kout features (the B operand of the next layer).  A layer is produced one 16-feature
+    // half at a time (acc: 20 accumulators instead of 40): half 0's output waits in the staging rows -- where the segment sums read
+    // it anyway -- until half 1's product has consumed D, and only then replaces D[0].  120 live accumulator registers in place
+    // of 160 leave the scheduler room to interleave the tanh chains of a unit with the LDS / MFMA latency of the unit before.
+    acc_t D[NT2][5], acc[5];
+    // One half of a layer's epilogue on `z` (pre-activations, features 16 a ..): v = tanh(z + b) (+ residual D[a]) -> `out` (z itself
+    // or D[a]) and the staging rows; then the segment sums of the half: per column the 16 x 16 tile [feature][pair] is read back as the
+    // A operand and multiplied with `ind` (four MFMAs), the sums land in pml.  No control flow and no fences inside: the LDS
+    // operations of a wave execute in order and the compiler keeps the order of may-alias accesses.
+    auto half_epilogue = [&](auto res_tag, int a, acc_t (&z)[5], acc_t (&resid)[5], acc_t (&out)[5], const T* __restrict__ bias) {
+        constexpr bool RES = decltype(res_tag)::value;
+        T bn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bn[r] = bias[16 * a + acc_row<T>(lane, r)];
+        // software pipeline over the five columns, spelled out (the compiler keeps LDS operations in source order and would put each
+        // unit's read -> MFMA -> write chain right behind its tanh): step c does the tanh of column c with the four MFMAs of column
+        // c - 1 between them (operands read from LDS a step earlier) and stores the sums of column c - 2
+        T ar[2][4];
+        typename std::conditional<M44, T, acc_t>::type sm[2];
+        auto seg_mfma = [&](int u, int r) {
+            if constexpr (M44) sm[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[u][r], ind[r], r == 0 ? 0.0 : sm[u], 0, 0, 0);
+            else sm[u] = mfma16(ar[u][r], ind[r], r == 0 ? acc_t{0, 0, 0, 0} : sm[u]);
+        };
+        auto seg_store = [&](int u, int c) {
+            if constexpr (M44) pm_dst[(16 * a + f44) * 5 + c] = sm[u];
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pm_dst[(16 * a + acc_row<T>(lane, r)) * 5 + c] = sm[u][r];
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            if (c < 5) {
+                T* st = stage + c * (16 * LD);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int r = 2 * h; r < 2 * h + 2; ++r) {
+                        T v = ds_tanh(z[c][r] + bn[r]);
+                        if (RES) v = (resid[c][r] + v) * rs2;
+                        out[c][r] = v;
+                        st[acc_row<T>(lane, r) * LD + lr] = v;
+                        if (c >= 1) seg_mfma((c - 1) & 1, r);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (c == 5) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) seg_mfma(0, r);
+            }
+            if (c >= 2) seg_store((c - 2) & 1, c - 2);
+            if (c < 5) {
+                const T* st = stage + c * (16 * LD);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) ar[c & 1][s4] = st[lr * LD + 4 * s4 + lq];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto reload_half0 = [&]() {                                   // D[0] <- the staging rows (each lane reads back what it wrote)
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D[0][c][r] = stage[(c * 16 + acc_row<T>(lane, r)) * LD + lr];
+    };
+    auto flush_sums = [&](T* __restrict__ pm) {
+#pragma unroll
+        for (int i = 0; i < (PMN + 63) / 64; ++i)
+            if (64 * i + lane < PMN) pm[64 * i + lane] = pml[64 * i + lane];
+    };
+    for (int l = 0; l < A.nl; ++l) {
+        const T* W = A.W[l];
+        const T* bias = A.b[l];
+        const bool res = A.res[l] != 0;
+#pragma unroll
+        for (int a2 = 0; a2 < NT2; ++a2) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[c] = acc_t{0, 0, 0, 0};
+            if (l == 0) {
+                const T* Hw = A.H0 + (size_t)w * A.Kin0 * 5 * NP + p0 + lr;
+                for (int ks = 0; ks < A.Kin0 / 4; ++ks) {
+                    const T av = W[(size_t)(4 * ks + lq) * Kout + 16 * a2 + lr];
+                    T bv[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) bv[c] = Hw[(size_t)((4 * ks + lq) * 5 + c) * NP];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) acc[c] = mfma16(av, bv[c], acc[c]);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < NT2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const T av = W[(size_t)(16 * a + acc_row<T>(lane, r)) * Kout + 16 * a2 + lr];
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) acc[c] = mfma16(av, D[a][c][r], acc[c]);
+                    }
+            }
+            // half a2 < NT2 - 1 leaves its output in acc (and the staging rows); the last half writes D[a2] in place
+            if (NT2 == 2 && a2 == 0) {
+                if (res) half_epilogue(std::true_type{}, 0, acc, D[0], acc, bias);
+                else half_epilogue(std::false_type{}, 0, acc, D[0], acc, bias);
+            } else {
+                if (NT2 == 2) reload_half0();
+                if (res) half_epilogue(std::true_type{}, a2, acc, D[a2], D[a2], bias);
+                else half_epilogue(std::false_type{}, a2, acc, D[a2], D[a2], bias);
+            }
+        }
+        flush_sums(A.PM[l] + ((size_t)w * (NP / 16) + pt) * PMN);
+    }
+}
+
 // log-determinant of every (walker, det) matrix of one determinant channel WITHOUT the inverse (Metropolis / log psi only):
 // LU with partial pivoting, FOUR LANES PER MATRIX -- lane p of a quad keeps rows R*p .. R*p+R-1 in registers (n <= 4R <= 16),
 // so a wave factorises 16 walkers' matrices at once with no LDS and no barriers.  The 16 walkers of a wave are consecutive

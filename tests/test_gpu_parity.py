@@ -656,6 +656,36 @@ def test_value_chain_wave_tiles_are_bit_identical(dtype, monkeypatch):
     np.testing.assert_allclose(out['4'][0][:3].double().cpu().numpy(), fx['logabs'][:3], atol=1e-9 if dtype == torch.float64 else 2e-3)
 
 
+@pytest.mark.parametrize('name,dtype', [('bcc_li', torch.float64), ('bcc_li', torch.float32), ('graphene_331', torch.float64),
+                                        ('diamond', torch.float32)])
+def test_fused_pair_stream_vs_layer_by_layer_kernels(name, dtype, monkeypatch):
+    """A log-psi forward runs every pair layer in one launch (k_pair_stream_val, csrc/ds_value.h: the activations stay in the
+    wave's registers, the segment sums over a tile's pairs are taken on the matrix pipe); DS_NO_PAIR_FUSE=1 (read at system
+    creation) keeps one k_two_layer launch per layer with DPP prefix sums.  Same activations; the partner sums are added in another
+    order, so log|psi| agrees to round-off of the working precision (float64: 1e-12 absolute on values of O(10..100); float32:
+    2e-4) -- on fixture walkers, where the reference-executed log|psi| bounds both, and on synthetic ones with a ragged tail."""
+    from deepsolid_amd import systems
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=dtype, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    nfx = min(3, len(fx['x']))
+    x = torch.as_tensor(np.concatenate([fx['x'][:nfx], systems.synthetic_walkers(cell, 83, seed=4)]), dtype=dtype, device='cuda')
+    out = []
+    for off in (False, True):
+        monkeypatch.delenv('DS_NO_PAIR_FUSE', raising=False)
+        if off:
+            monkeypatch.setenv('DS_NO_PAIR_FUSE', '1')
+        la, ph = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), dtype).logpsi(dp, x)
+        out.append((la.double().cpu().numpy(), ph.double().cpu().numpy()))
+    tol = 1e-12 if dtype == torch.float64 else 2e-4
+    assert np.isfinite(out[0][0]).all()
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=tol * max(1.0, np.abs(out[1][0]).max()))
+    dph = np.angle(np.exp(1j * (out[0][1] - out[1][1])))
+    assert np.abs(dph).max() < (1e-10 if dtype == torch.float64 else 2e-3)
+    np.testing.assert_allclose(out[0][0][:nfx], fx['logabs'][:nfx], atol=1e-9 if dtype == torch.float64 else 2e-3)
+
+
 @pytest.mark.parametrize('nelec', [(12, 10), (10, 6)])
 def test_value_chain_log_det_channels_of_different_sizes(nelec):
     """k_det_lu_val factorises both spin channels' matrices in one launch when they take the same register instance (12 x 12 and
