@@ -681,9 +681,41 @@ def test_fused_pair_stream_vs_layer_by_layer_kernels(name, dtype, monkeypatch):
     tol = 1e-12 if dtype == torch.float64 else 2e-4
     assert np.isfinite(out[0][0]).all()
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=tol * max(1.0, np.abs(out[1][0]).max()))
-    dph = np.angle(np.exp(1j * (out[0][1] - out[1][1])))
-    assert np.abs(dph).max() < (1e-10 if dtype == torch.float64 else 2e-3)
+    assert np.abs(out[0][1] - out[1][1]).max() < (1e-10 if dtype == torch.float64 else 2e-3)      # phase = (re, im) of psi / |psi|
     np.testing.assert_allclose(out[0][0][:nfx], fx['logabs'][:nfx], atol=1e-9 if dtype == torch.float64 else 2e-3)
+
+
+@pytest.mark.parametrize('nelec,hidden_dims,use_last', [((12, 12), ((64, 16),) * 4, False),                    # three fused pair layers, 16 wide
+                                                        ((24, 0), ((64, 32),) * 3, False),                     # one spin channel: one segment per electron
+                                                        ((13, 9), ((64, 32), (64, 32), (64, 32)), True),       # use_last_layer: three pair layers feed the head; ragged segments
+                                                        ((12, 12), ((64, 32), (64, 32), (64, 16)), True),      # unequal pair widths: the layer-by-layer kernels run
+                                                        ((8, 8), ((64, 32), (64, 32)), False)])                # one pair layer; 256 pairs = 16 whole tiles
+def test_fused_pair_stream_other_shapes_vs_oracle(nelec, hidden_dims, use_last, monkeypatch):
+    """k_pair_stream_val on the shapes the fixtures do not hold: 16-wide pairs, one to three fused layers, one spin channel,
+    segments of 8 / 9 / 13 / 24 partners (two or three segments per 16-pair tile), use_last_layer -- log|psi| and the phase
+    against the oracle network (float64, 1e-10) and against the layer-by-layer kernels (DS_NO_PAIR_FUSE=1)."""
+    from deepsolid_amd import systems
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('bcc_li', nelec=nelec)
+    net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=hidden_dims, determinants=2, use_last_layer=use_last)
+    params = make_test_params(41, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    dp = dev_params(params)
+    x64 = systems.synthetic_walkers(cell, 7, seed=12)
+    x = torch.as_tensor(x64, device='cuda')
+    ref = oracle_net(cell, klist, net_kw, 'eval_phase_and_slogdet').apply(onet.params_to_torch(params), tt(x64[0]))
+    out = []
+    for off in (False, True):
+        monkeypatch.delenv('DS_NO_PAIR_FUSE', raising=False)
+        if off:
+            monkeypatch.setenv('DS_NO_PAIR_FUSE', '1')
+        la, ph = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).logpsi(dp, x)
+        out.append((la.cpu().numpy(), ph.cpu().numpy()))
+        assert abs(out[-1][0][0] - float(ref[1])) < 1e-10, (out[-1][0][0], float(ref[1]))
+        assert abs(complex(out[-1][1][0, 0], out[-1][1][0, 1]) - complex(ref[0])) < 1e-10      # phase = (re, im) of psi / |psi|
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-10)
 
 
 @pytest.mark.parametrize('nelec', [(12, 10), (10, 6)])
