@@ -103,10 +103,14 @@ struct ds_system {
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
+    int64_t val_i8_min_tiles = 512;   // (group, electron) tiles from which they do: two per CU (DS_I8_VAL_MIN_TILES overrides: measurements)
+    bool use_i8_val = true;           // DS_NO_I8_VAL unset: the value chain's residual hidden layers run as the int8 split too (large batches)
     bool use_pair_fuse = true;        // DS_NO_PAIR_FUSE unset: a log-psi forward runs all pair layers in one launch (k_pair_stream_val, ds_value.h)
     bool use_ldsb = true;             // DS_NO_LDSB unset: float32 cells with more than 10 slot tiles run the orbital head with LDS-staged jet rows (ds_ldsb.h)
     bool use_i8 = true;               // DS_NO_I8 unset: dense hidden layers of the 5-slot-tile float64 cells run their per-electron contraction as an int8 split (ds_i8.h)
-    void* i8_wp = nullptr;            // digit planes of that layer's weights + (behind them) the 256 column scales, refilled at every call
+    void* i8_wp = nullptr;            // per layer: digit planes of its weights + (behind them) the 256 column scales; filled once per C-ABI call
+    uint64_t call_seq = 0;            // counts the C-ABI calls that take `params` (the planes of layer l are current when i8_prepped[l] == call_seq)
+    uint64_t i8_prepped[DS_MAX_LAYERS];   // (set to ~0 at creation: never equal to a call count)
     int n_cu = 256;                   // compute units of the device (grid of the persistent int8 layer kernel)
     bool use_wide = true;             // DS_NO_WIDE unset: the chunked kernels of ds_wide.h for more than 10 slot tiles where they are faster
     bool wide_all = false;            // DS_WIDE_ALL: ... everywhere (tests, A/B runs)
@@ -424,6 +428,18 @@ inline bool int8_layer(const ds_system* s, int l) {
     return s->dtype == 0 && s->use_i8 && l >= 1 && s->res1[l] && S.P == ds::i8::P && S.h1[l + 1] == ds::i8::NOUT && Kloc == 320;
 }
 
+// digit planes + column scales of layer l's per-electron weights: prepared by the first launch of a C-ABI call that needs them (the
+// 20 forwards of an mcmc_step, the chunks of a local-energy batch and the value / energy chains of one call share them)
+inline void i8_prepare(ds_system* s, int l, const double* Wloc, int Kloc, int Nout, hipStream_t st, uint8_t** wp, double** sw) {
+    const size_t slot = ds::i8::wp_bytes(64 * 5) + ds::i8::NOUT * sizeof(double);
+    *wp = (uint8_t*)s->i8_wp + (size_t)l * slot;
+    *sw = (double*)(*wp + ds::i8::wp_bytes(64 * 5));
+    if (s->i8_prepped[l] != s->call_seq) {
+        hipLaunchKernelGGL(ds::i8::k_i8_prep_w, dim3(ds::i8::NOUT / 16), dim3(256), 0, st, Wloc, Kloc, Nout, *wp, *sw);
+        s->i8_prepped[l] = s->call_seq;
+    }
+}
+
 // The forward-Laplacian chain on a chunk of Bc walkers.
 template <typename T>
 int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, hipStream_t st, T* out_ke, T* out_logabs,
@@ -555,9 +571,8 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             } else if (int8_layer(s, l)) {
                 // dense residual layer of the 5-slot-tile float64 cells: the per-electron contraction as an error-free split on the
                 // int8 matrix pipe (ds_i8.h); float64 in, float64 out, same shared term, same epilogue
-                uint8_t* wp = (uint8_t*)s->i8_wp;
-                double* sw = (double*)(wp + ds::i8::wp_bytes(64 * 5));
-                hipLaunchKernelGGL(ds::i8::k_i8_prep_w, dim3(ds::i8::NOUT / 16), dim3(256), 0, st, (const double*)blk(s->i_wloc[l]), Kloc, Nout, wp, sw);
+                uint8_t* wp; double* sw;
+                i8_prepare(s, l, (const double*)blk(s->i_wloc[l]), Kloc, Nout, st, &wp, &sw);
                 const int ntiles = (int)(Bc * S.N);
                 const dim3 igrid((unsigned)std::min<int64_t>(ntiles, s->n_cu));
                 hipLaunchKernelGGL((ds::i8::k_layer_i8<5, 2>), igrid, dim3(512), ds::i8::lds_bytes(), st, (const double*)c.G[gi], gts, (const uint4*)wp,
@@ -833,7 +848,16 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
 #define DS_VHID(NBV) { dim3 hb; unsigned hz; val_geom(Nout, NBV, &hb, &hz); \
             hipLaunchKernelGGL((ds::k_jet_gemm<T, NBV, 5, 4>), dim3(S.N, (unsigned)ng, hz), hb, (ds::gemm_stash_bytes<T, NBV, 5>(hb.x)), st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc, \
                                (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, gws, gts, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{}); }
-        if (s->res1[l]) {
+        // residual hidden layers of the 256-feature networks with enough (group, electron) tiles to give every CU's persistent workgroup
+        // two or more: the int8 split of the forward-Laplacian chain (ds_i8.h) with the value epilogue -- 43 us per tile against the
+        // float64 MFMA kernel's 73 (the float64 MFMA shares the FP64 datapath with the tanh polynomials, the int8 MFMA does not)
+        if (sizeof(T) == 8 && int8_layer(s, l) && s->use_i8_val && (int64_t)S.N * ng >= (int64_t)s->val_i8_min_tiles) {
+            uint8_t* wp; double* sw;
+            i8_prepare(s, l, (const double*)blk(s->i_wloc[l]), Kloc, Nout, st, &wp, &sw);
+            const int ntiles = (int)(S.N * ng);
+            hipLaunchKernelGGL((ds::i8::k_layer_i8<5, 4>), dim3((unsigned)std::min<int64_t>(ntiles, s->n_cu)), dim3(512), ds::i8::lds_bytes(), st, (const double*)Gin, gts,
+                               (const uint4*)wp, (const double*)sw, (const double*)ZB, S.N, (double*)Gout, ntiles);
+        } else if (s->res1[l]) {
             if (nbh == 4) DS_VHID(4) else if (nbh == 2) DS_VHID(2) else DS_VHID(1)
         } else
 #undef DS_VHID
@@ -1509,7 +1533,7 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
         int devid = 0;
         if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.multiProcessorCount > 0)
             s->n_cu = prop.multiProcessorCount;
-        if (hipMalloc(&s->i8_wp, ds::i8::wp_bytes(64 * 5) + ds::i8::NOUT * sizeof(double)) != hipSuccess) {
+        if (hipMalloc(&s->i8_wp, (size_t)DS_MAX_LAYERS * (ds::i8::wp_bytes(64 * 5) + ds::i8::NOUT * sizeof(double))) != hipSuccess) {
             ds_system_destroy(s);
             return fail("hipMalloc of the int8 layer's weight planes failed");
         }
@@ -1527,6 +1551,9 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
     s->use_i8 = getenv("DS_NO_I8") == nullptr;
     s->use_ldsb = getenv("DS_NO_LDSB") == nullptr;
     s->use_pair_fuse = getenv("DS_NO_PAIR_FUSE") == nullptr;
+    s->use_i8_val = getenv("DS_NO_I8_VAL") == nullptr;
+    for (int l = 0; l < DS_MAX_LAYERS; ++l) s->i8_prepped[l] = ~(uint64_t)0;
+    if (const char* e = getenv("DS_I8_VAL_MIN_TILES")) s->val_i8_min_tiles = atoll(e);
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     s->use_wide = getenv("DS_NO_WIDE") == nullptr;
     s->wide_all = getenv("DS_WIDE_ALL") != nullptr;
@@ -1586,6 +1613,7 @@ int64_t ds_workspace_bytes(const ds_system* s, int64_t B) {
 
 int ds_local_energy(ds_system* s, const void* params, const void* x, int64_t B, void* out_ke, void* out_ewald, void* out_logabs,
                     void* out_phase, void* ws, int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !ws) return fail("null argument");
     if (B <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -1595,6 +1623,7 @@ int ds_local_energy(ds_system* s, const void* params, const void* x, int64_t B, 
 
 int ds_logpsi(ds_system* s, const void* params, const void* x, int64_t B, void* out_logabs, void* out_phase, void* ws,
               int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !ws) return fail("null argument");
     if (B <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -1604,6 +1633,7 @@ int ds_logpsi(ds_system* s, const void* params, const void* x, int64_t B, void* 
 
 int ds_logpsi_grad(ds_system* s, const void* params, const void* x, int64_t B, void* out_logabs, void* out_phase, void* out_grad,
                    void* ws, int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !ws || !out_grad) return fail("null argument");
     if (B <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -1624,6 +1654,7 @@ int64_t ds_vjp_workspace_bytes(const ds_system* s, int64_t B) {
 
 int ds_logpsi_vjp(ds_system* s, const void* params, const void* x, int64_t B, const void* cot, void* grad, void* out_logabs,
                   void* out_phase, void* ws, int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !cot || !grad || !ws) return fail("null argument");
     hipStream_t st = (hipStream_t)stream;
     if (B <= 0) {
@@ -1758,6 +1789,7 @@ int64_t ds_mcmc_workspace_bytes(const ds_system* s, int64_t B) {
 int ds_mcmc_step(ds_system* s, const void* params, void* x, void* lp, int64_t B, int steps, double width, uint64_t philox_seed,
                  uint64_t philox_offset, const void* normals, const void* uniforms, int lp_valid, void* n_accept, void* ws,
                  int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !lp || !n_accept || !ws) return fail("null argument");
     if ((normals == nullptr) != (uniforms == nullptr)) return fail("normals and uniforms must be given together (or both NULL)");
     if (steps < 0) return fail("steps must be >= 0");
@@ -1772,6 +1804,7 @@ int ds_mcmc_step(ds_system* s, const void* params, void* x, void* lp, int64_t B,
 int ds_mcmc_step_one_electron(ds_system* s, const void* params, void* x, void* lp, int64_t B, int moves, int first_electron,
                               double width, uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms,
                               int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !lp || !n_accept || !ws) return fail("null argument");
     if ((normals == nullptr) != (uniforms == nullptr)) return fail("normals and uniforms must be given together (or both NULL)");
     if (moves < 0 || first_electron < 0) return fail("moves and first_electron must be >= 0");
@@ -1786,6 +1819,7 @@ int ds_mcmc_step_one_electron(ds_system* s, const void* params, void* x, void* l
 int ds_mcmc_step_asymmetric(ds_system* s, const void* params, void* x, void* lp, int64_t B, int steps, double width, const void* atoms,
                             int n_atoms, uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms,
                             int lp_valid, void* n_accept, void* ws, int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !lp || !n_accept || !ws || !atoms) return fail("null argument");
     if ((normals == nullptr) != (uniforms == nullptr)) return fail("normals and uniforms must be given together (or both NULL)");
     if (steps < 0 || n_atoms < 1) return fail("steps must be >= 0 and n_atoms >= 1");
@@ -1800,6 +1834,7 @@ int ds_mcmc_step_asymmetric(ds_system* s, const void* params, void* x, void* lp,
 int ds_mcmc_step_importance(ds_system* s, const void* params, void* x, void* lp, int64_t B, int steps, double width,
                             uint64_t philox_seed, uint64_t philox_offset, const void* normals, const void* uniforms, int lp_valid,
                             void* n_accept, void* ws, int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !lp || !n_accept || !ws) return fail("null argument");
     if ((normals == nullptr) != (uniforms == nullptr)) return fail("normals and uniforms must be given together (or both NULL)");
     if (steps < 0) return fail("steps must be >= 0");
@@ -1832,6 +1867,7 @@ void ds_philox_host(uint64_t seed, uint64_t offset, uint64_t step, uint64_t inde
 
 int ds_orbitals(ds_system* s, const void* params, const void* x, int64_t B, void* out_up, void* out_dn, void* ws, int64_t ws_bytes,
                 void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !ws || !out_up) return fail("null argument");
     if (B <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -1841,6 +1877,7 @@ int ds_orbitals(ds_system* s, const void* params, const void* x, int64_t B, void
 
 int64_t ds_debug_stage(ds_system* s, const void* params, const void* x, int64_t B, const char* stage, void* out, int64_t out_elems,
                        void* ws, int64_t ws_bytes, void* stream) {
+    if (s) ++s->call_seq;
     if (!s || !params || !x || !stage || !out || !ws) { fail("null argument"); return -1; }
     static const struct { const char* name; int stop; } names[] = {
         {"g0", STOP_G0}, {"g1", STOP_G1}, {"g2", STOP_G2}, {"g3", STOP_G3}, {"h2_0", STOP_H2_0}, {"h2_1", STOP_H2_1},

@@ -171,7 +171,8 @@ __device__ __forceinline__ void slice_chunk(const double* __restrict__ R, const 
 
 // The layer.  X: input tiles [tile][ldx rows][P] (the first 64 NCH rows are contracted, rows 0 .. 255 are the residual);
 // Sb: shared term + bias [walker][256][P] (walker = tile / N); Gout: output tiles, same strides.  EPI = 2: residual layer
-// (h_out = (h_in + tanh-chain(z)) / sqrt 2), EPI = 1: no residual.  grid = CUs (a multiple of 8 for the XCD-aware tile order; fewer when there are fewer tiles), block = 512, LDS = lds_bytes(); ntiles = walkers x N.
+// (h_out = (h_in + tanh-chain(z)) / sqrt 2), EPI = 1: no residual, EPI = 4: the value chain's residual layer (h_out = (h_in + tanh z) / sqrt 2
+// in every column; tiles = (80-walker group, electron), Sb per group).  grid = CUs (a multiple of 8 for the XCD-aware tile order; fewer when there are fewer tiles), block = 512, LDS = lds_bytes(); ntiles = walkers x N.
 template <int NCH, int EPI>
 __global__ void __launch_bounds__(512, 1) k_layer_i8(const double* __restrict__ X, size_t tile_stride, const uint4* __restrict__ WP,
                                                      const double* __restrict__ SW, const double* __restrict__ Sb, int N,
@@ -321,7 +322,9 @@ __global__ void __launch_bounds__(512, 1) k_layer_i8(const double* __restrict__ 
                     }
                 };
                 layer_epilogue<double, 1, ST, 2, 0>(zh, (const double*)nullptr, Go, (const double*)nullptr, n0 + 16 * q, lane_e, P, rf);
-            } else
+            } else if (EPI == 4)     // value chain (the slot axis carries 80 walkers): tanh of every column + residual, rows fetched by the epilogue
+                layer_epilogue<double, 1, ST, 4, 0>(zh, Gi, Go, (const double*)nullptr, n0 + 16 * q, lane_e, P);
+            else
                 layer_epilogue<double, 1, ST, 1, 0>(zh, (const double*)nullptr, Go, (const double*)nullptr, n0 + 16 * q, lane_e, P);
         }
 #pragma unroll

@@ -685,6 +685,37 @@ def test_fused_pair_stream_vs_layer_by_layer_kernels(name, dtype, monkeypatch):
     np.testing.assert_allclose(out[0][0][:nfx], fx['logabs'][:nfx], atol=1e-9 if dtype == torch.float64 else 2e-3)
 
 
+def test_int8_split_value_chain_layers_vs_float64_kernels(monkeypatch):
+    """With 512 or more (80-walker group, electron) tiles the residual hidden layers of a log-psi forward run as the int8 split of
+    csrc/ds_i8.h with the value epilogue (k_layer_i8<5, 4>: tanh of every walker column + residual); DS_NO_I8_VAL=1 keeps the
+    float64 MFMA kernels.  1843 bcc-Li walkers (24 groups x 24 electrons = 576 tiles, the last group ragged): log|psi| and phase of
+    both paths agree to 1e-10 (the split is exact to ~1e-12 of a column's largest entry), the fixture walkers hold the
+    reference-executed log|psi|, and a NaN coordinate poisons exactly its own walker on both paths."""
+    from deepsolid_amd import systems
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case('bcc_li')
+    dp = dev_params(params)
+    x64 = np.concatenate([fx['x'][:3], systems.synthetic_walkers(cell, 1840, seed=21)])
+    x64[100, 5] = np.nan
+    x = torch.as_tensor(x64, device='cuda')
+    out = []
+    for off in (False, True):
+        monkeypatch.delenv('DS_NO_I8_VAL', raising=False)
+        if off:
+            monkeypatch.setenv('DS_NO_I8_VAL', '1')
+        la, ph = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).logpsi(dp, x)
+        out.append((la.cpu().numpy(), ph.cpu().numpy()))
+    ok = np.ones(len(x64), bool)
+    ok[100] = False
+    for la, ph in out:
+        assert np.isnan(la[100]) and np.isfinite(la[ok]).all()
+        np.testing.assert_allclose(la[:3], fx['logabs'][:3], atol=1e-9)
+    np.testing.assert_allclose(out[0][0][ok], out[1][0][ok], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(out[0][1][ok], out[1][1][ok], rtol=0, atol=1e-9)
+    assert not np.array_equal(out[0][0][ok], out[1][0][ok])          # (the two paths really are different kernels)
+
+
 @pytest.mark.parametrize('nelec,hidden_dims,use_last', [((12, 12), ((64, 16),) * 4, False),                    # three fused pair layers, 16 wide
                                                         ((24, 0), ((64, 32),) * 3, False),                     # one spin channel: one segment per electron
                                                         ((13, 9), ((64, 32), (64, 32), (64, 32)), True),       # use_last_layer: three pair layers feed the head; ragged segments
