@@ -15,8 +15,11 @@
  *     caller (torch tensors), element type given by ds_system_desc.dtype
  *     (0 = float64, 1 = float32); walkers are (B, 3*N) row-major, B = batch;
  *   - `stream` is a hipStream_t passed as void* (0 = default stream); nothing is
- *     allocated or synchronised after ds_system_create; calls on distinct streams
- *     with distinct workspaces are independent;
+ *     allocated or synchronised after ds_system_create.  A handle carries device
+ *     scratch of its own (the int8 digit planes of the hidden-layer weights, refilled
+ *     by the first launch of every call that takes `params`): calls on ONE handle
+ *     must be issued from one host thread and complete in issue order (one stream, or
+ *     streams ordered by events); for concurrent streams create one handle per stream;
  *   - no torch types appear anywhere in this interface.
  */
 #ifndef DEEPSOLID_HIP_H
