@@ -584,15 +584,18 @@ template <typename T> struct LrArgs {
     const T* W0; const T* S0;            // layer-0 per-electron weights [K0loc][Kh], its shared term [walker][Kh][P]
     int dbg;                             // timing experiments (make EXP=1 only): 1 no epilogue, 2 no phase 1, 4 no phase 2, 8 no S1 loads
 };
-template <int NB, int NC> constexpr int lr_ncp() { return 16 * NC + 1; }
-template <typename T, int NB, int NC> inline size_t lr_lds_bytes(unsigned threads, int Kh) {
-    return ((size_t)2 * Kh + (size_t)(threads / 64) * 16 * NB * lr_ncp<NB, NC>()) * sizeof(T);
+// NC full 16-column tiles of C + NG groups of 4 columns behind them (float64 only: the groups are v_mfma_f64_4x4x4_4b products, 16
+// cycles for 16 features x 4 columns where a 16x16x4 tile of mostly padding costs 64: K0 + 4 = 24 columns are one tile + two groups)
+template <int NB, int NC, int NG = 0> constexpr int lr_ncp() { return 16 * NC + 4 * NG + 1; }
+template <typename T, int NB, int NC, int NG = 0> inline size_t lr_lds_bytes(unsigned threads, int Kh) {
+    return ((size_t)2 * Kh + (size_t)(threads / 64) * 16 * NB * lr_ncp<NB, NC, NG>()) * sizeof(T);
 }
 
-template <typename T, int NB, int ST, int NC, bool RES>
+template <typename T, int NB, int ST, int NC, bool RES, int NG = 0>
 __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)) k_layer1_lr(LrArgs<T> A) {
     typedef typename Acc4<T>::type acc_t;
-    constexpr int NCP = lr_ncp<NB, NC>();
+    static_assert(NG == 0 || sizeof(T) == 8, "column groups: float64 only");
+    constexpr int NCP = lr_ncp<NB, NC, NG>(), LDW = 16 * (NC + (NG > 0 ? 1 : 0));      // LDW: row length of W0T (whole column tiles)
     // (placement as in k_jet_gemm: the tiles of one walker on one XCD, column blocks of a tile side by side)
     int tile = blockIdx.x, w = blockIdx.y;
     if ((gridDim.y & 7) == 0) {
@@ -623,21 +626,29 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
     if (n0 >= Nout) return;
     // ---------------- phase 1: C[m][c] = sum_n W1[n][m] B1[n][c]
     acc_t c1[NB][NC];
+    T c4[NB][NG > 0 ? NG : 1];               // column groups: D_blk[i][j] = C[feature 4 blk + i][column 16 NC + 4 g + j] in lane 16 i + 4 blk + j
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
+    for (int a = 0; a < NB; ++a) {
 #pragma unroll
         for (int s = 0; s < NC; ++s) c1[a][s] = acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) c4[a][g] = 0;
+    }
     {
-        T av[4][NB], wv[4][NC];
+        T av[4][NB], wv[4][NC], w4[4][NG > 0 ? NG : 1];
         const T* Wl = A.W1 + n0 + (size_t)lq * Nout + lr;
-        const T* Tl = A.W0T + lq * (16 * NC) + lr;
+        const T* Tl = A.W0T + lq * LDW + lr;
+        const T* T4 = A.W0T + lq * LDW + 16 * NC + (lr & 3);      // the 4-block B operand: B_blk[k][j] in lane 16 k + 4 blk + j, the same for every block
         auto load_set = [&](int u) {
 #pragma unroll
             for (int a = 0; a < NB; ++a) av[u][a] = Wl[16 * a];
 #pragma unroll
             for (int s = 0; s < NC; ++s) wv[u][s] = Tl[16 * s];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) w4[u][g] = T4[4 * g];
             Wl += (size_t)4 * Nout;
-            Tl += 4 * 16 * NC;
+            Tl += 4 * LDW;
+            T4 += 4 * LDW;
         };
         auto step = [&](int u, int ks) {
             typedef T vec2 __attribute__((ext_vector_type(2)));
@@ -653,6 +664,16 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
             for (int a = 0; a < NB; ++a)
 #pragma unroll
                 for (int s = 0; s < NC; ++s) c1[a][s] = mfma16(av[u][a], bv[s], c1[a][s]);
+            if constexpr (NG > 0) {
+                // (the A operand of the 4-block form -- A_blk[i][k] in lane 16 k + 4 blk + i -- is the 16x16x4 A operand as it stands)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int c = 16 * NC + 4 * g + (lr & 3);
+                    const T b4 = c == K0 ? y : (c == K0 + 1 ? yo[1] : d1 * w4[u][g]);
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) c4[a][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u][a], b4, c4[a][g], 0, 0, 0);
+                }
+            }
         };
         const int nks = DS_EXP(A.dbg & 2) ? 4 : Kh / 4;                       // (Kh is a multiple of 16: launcher)
 #pragma unroll
@@ -672,6 +693,10 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
         for (int s = 0; s < NC; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cl[(16 * a + acc_row<T>(lane, r)) * NCP + 16 * s + lr] = c1[a][s][r];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) Cl[(16 * a + 4 * ((lane >> 2) & 3) + lq) * NCP + 16 * NC + 4 * g + (lane & 3)] = c4[a][g];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---------------- phase 2

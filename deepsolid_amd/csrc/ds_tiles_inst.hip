@@ -50,6 +50,18 @@ template <typename T, int NB, int ST> struct TileImpl {
         hipLaunchKernelGGL((k_shared_term<T, NB, ST>), grid, block, lds, st, S, G, Wsh, Kh, Sb, Nout, P, bias, bias_all_slots);
     }
     static void layer1_lr(int nc, bool res, dim3 grid, dim3 block, hipStream_t st, const LrArgs<T>& a) {
+        // float64, up to 10 slot tiles: a last column tile with 4 or 8 columns in use (K0 + 4 = 16 (nc - 1) + 4 or + 8) as one or two
+        // four-block MFMA groups
+        if constexpr (sizeof(T) == 8 && ST <= 10) {
+            const int rem = a.K0loc + a.K0sh + 4 - 16 * (nc - 1);
+            if (nc >= 2 && nc <= 3 && (rem == 4 || rem == 8)) {
+#define DS_LRG(NCV, NGV, RESV) hipLaunchKernelGGL((k_layer1_lr<T, NB, ST, NCV, RESV, NGV>), grid, block, (lr_lds_bytes<T, NB, NCV, NGV>(block.x, a.Kh)), st, a)
+                if (nc == 2) { if (rem == 4) { if (res) DS_LRG(1, 1, true); else DS_LRG(1, 1, false); } else { if (res) DS_LRG(1, 2, true); else DS_LRG(1, 2, false); } }
+                else { if (rem == 4) { if (res) DS_LRG(2, 1, true); else DS_LRG(2, 1, false); } else { if (res) DS_LRG(2, 2, true); else DS_LRG(2, 2, false); } }
+#undef DS_LRG
+                return;
+            }
+        }
 #define DS_LR(NCV, RESV) hipLaunchKernelGGL((k_layer1_lr<T, NB, ST, NCV, RESV>), grid, block, (lr_lds_bytes<T, NB, NCV>(block.x, a.Kh)), st, a)
         if (nc <= 2) { if (res) DS_LR(2, true); else DS_LR(2, false); }
         else if (nc == 3) { if (res) DS_LR(3, true); else DS_LR(3, false); }
