@@ -551,7 +551,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 // first hidden layer on the low-rank form of the layer-0 output (ds_gemm.h: k_layer1_lr)
                 const ds::LrArgs<T> la{c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, c.MEAN[0], (size_t)K0sh * S.P, K0loc, K0sh,
                                        (const T*)s->lr_w0t, c.G[gi], gws, gts, blk(s->i_wloc[l]), Kh, S.nch * K2, c.G[gi ^ 1], gws, gts, Sl,
-                                       Nout, S.P, S.N, c.YO, L.YO, blk(s->i_wloc[0]), c.ZB, s->dbg >> 8};
+                                       Nout, S.P, S.N, c.YO, L.YO, blk(s->i_wloc[0]), c.ZB, s->dbg >> 8, S.n_up, S.nch};
                 if (!(wide && to->layer1_lr_wide(lr_nc, res, s->wide_all, wgrid, wblock, st, la))) to->layer1_lr(lr_nc, res, lgrid, block, st, la);
             } else if (lr_on && l == 0) {
                 // layer 0 without its dense output: (y, oL) per electron + the spin means of the output (ds_gemm.h).  One kernel when

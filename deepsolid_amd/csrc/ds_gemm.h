@@ -583,6 +583,7 @@ template <typename T> struct LrArgs {
     const T* YO; size_t yo_ws;           // [walker][tile][Kh][2] = (y_n, oL_n)  (k_layer0_stats)
     const T* W0; const T* S0;            // layer-0 per-electron weights [K0loc][Kh], its shared term [walker][Kh][P]
     int dbg;                             // timing experiments (make EXP=1 only): 1 no epilogue, 2 no phase 1, 4 no phase 2, 8 no S1 loads
+    int n_up, nch;                       // spin-up electrons, spin channels: which slot tiles of a pair-mean row can be non-zero (k_layer1_lr)
 };
 // NC full 16-column tiles of C + NG groups of 4 columns behind them (float64 only: the groups are v_mfma_f64_4x4x4_4b products, 16
 // cycles for 16 features x 4 columns where a 16x16x4 tile of mostly padding costs 64: K0 + 4 = 24 columns are one tile + two groups)
@@ -741,18 +742,40 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
             for (int s = 0; s < ST; ++s) bv[u][s] = xp[16 * s];
             ++kl;
         };
+        // The pair-mean rows of partner spin sp are zero outside slot tile 0 (slots 0, 1), the tiles of the electron's own three
+        // slots and the tiles of the partners' slots (k_m2_expand writes exact zeros elsewhere): with 12 + 12 electrons a spin-up row
+        // fills tiles 0 .. 2 (+ the own tile of a spin-down electron), a spin-down row tiles 0, 2 .. 4: the products on the other
+        // tiles add exact zeros and are skipped (wave-uniform mask per k-step; bit-identical).
+        unsigned tmask[2];
+        {
+            const int n_dn = A.n_tiles - A.n_up;
+            const unsigned own = (1u << ((2 + 3 * tile) >> 4)) | (1u << ((4 + 3 * tile) >> 4));
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const int j0 = sp == 0 ? 0 : A.n_up, ns = (sp == 0 || A.nch == 1) ? (A.nch == 1 ? A.n_tiles : A.n_up) : n_dn;
+                const int lo = (2 + 3 * j0) >> 4, hi = (4 + 3 * (j0 + ns - 1)) >> 4;
+                tmask[sp] = 1u | own | (((2u << hi) - 1u) & ~((1u << lo) - 1u));
+            }
+        }
+        const int nm2s = A.nch > 1 ? nm2 / 2 : nm2;            // k-steps of the first partner spin's rows
         auto step = [&](int u, int k) {
             const bool low = k >= nm2;
             const int c = low ? 4 * (k - nm2) : 0;
+            const unsigned m = low ? ~0u : tmask[k < nm2s ? 0 : 1];
             T b0 = bv[u][0];
             b0 = (low && lr < 2) ? T(0) : b0;
+            T aa[NB];
 #pragma unroll
             for (int a = 0; a < NB; ++a) {
                 const T cl = Ca[16 * a * NCP + c];
-                const T aa = low ? cl : av[u][a];
-#pragma unroll
-                for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(aa, s == 0 ? b0 : bv[u][s], acc[a][s]);
+                aa[a] = low ? cl : av[u][a];
             }
+#pragma unroll
+            for (int s = 0; s < ST; ++s)
+                if ((m >> s) & 1) {
+#pragma unroll
+                    for (int a = 0; a < NB; ++a) acc[a][s] = mfma16(aa[a], s == 0 ? b0 : bv[u][s], acc[a][s]);
+                }
         };
         // (nk >= NSET: at least one pair-mean k-step and K0 >= 8)
 #pragma unroll
