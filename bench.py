@@ -490,7 +490,7 @@ def main():
         f_lr = n_e * (2.0 * h1 * h1 * (k0loc + k0sh + 2) + 2.0 * (k0loc + k0sh + nch * h2) * h1 * d_slots + 2.0 * k0loc * h1 * d_slots)
         lr_ms = kms['single_lr']
         lr_ach = f_lr * args.batch / (lr_ms * 1e-3) / 1e12
-        lr_obj = {'bound': 'mfma', 'kernel': hidden_name.replace('k_jet_gemm', 'k_layer1_lr').replace(',2>', ',NC,true>') +
+        lr_obj = {'bound': 'mfma', 'kernel': gemm_instance(n_e, dtype, 2)[0].replace('k_jet_gemm', 'k_layer1_lr').replace(',2>', ',NC,true,NG>') +
                   ' (first hidden layer on the rank-%d form of the layer-0 output)' % (k0loc + k0sh),
                   'achieved': lr_ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': lr_ach / peak, 'traffic': None,
                   'flops_per_walker': f_lr, 'dense_layer_flops_per_walker': f_layer,
