@@ -713,7 +713,8 @@ def test_int8_split_value_chain_layers_vs_float64_kernels(monkeypatch):
         np.testing.assert_allclose(la[:3], fx['logabs'][:3], atol=1e-9)
     np.testing.assert_allclose(out[0][0][ok], out[1][0][ok], rtol=0, atol=1e-10)
     np.testing.assert_allclose(out[0][1][ok], out[1][1][ok], rtol=0, atol=1e-9)
-    assert not np.array_equal(out[0][0][ok], out[1][0][ok])          # (the two paths really are different kernels)
+    if not os.environ.get('DS_NO_I8'):                               # (a suite run with DS_NO_I8=1 forced has no int8 kernel on either side)
+        assert not np.array_equal(out[0][0][ok], out[1][0][ok])      # the two paths really are different kernels
 
 
 @pytest.mark.parametrize('nelec,hidden_dims,use_last', [((12, 12), ((64, 16),) * 4, False),                    # three fused pair layers, 16 wide
