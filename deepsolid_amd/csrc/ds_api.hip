@@ -427,6 +427,12 @@ inline bool int8_layer(const ds_system* s, int l) {
     const int Kloc = S.h1[l] + S.nch * S.h2[l];
     return s->dtype == 0 && s->use_i8 && l >= 1 && s->res1[l] && S.P == ds::i8::P && S.h1[l + 1] == ds::i8::NOUT && Kloc == 320;
 }
+// (the value chain's column axis is 80 walkers whatever the electron count: any float64 cell with such a layer)
+inline bool int8_value_layer(const ds_system* s, int l) {
+    const ds::SysDev<double>& S = s->sd;
+    const int Kloc = S.h1[l] + S.nch * S.h2[l];
+    return s->dtype == 0 && s->use_i8 && s->use_i8_val && l >= 1 && s->res1[l] && ds::PV == ds::i8::P && S.h1[l + 1] == ds::i8::NOUT && Kloc == 320;
+}
 
 // digit planes + column scales of layer l's per-electron weights: prepared by the first launch of a C-ABI call that needs them (the
 // 20 forwards of an mcmc_step, the chunks of a local-energy batch and the value / energy chains of one call share them)
@@ -851,7 +857,7 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         // residual hidden layers of the 256-feature networks with enough (group, electron) tiles to give every CU's persistent workgroup
         // two or more: the int8 split of the forward-Laplacian chain (ds_i8.h) with the value epilogue -- 43 us per tile against the
         // float64 MFMA kernel's 73 (the float64 MFMA shares the FP64 datapath with the tanh polynomials, the int8 MFMA does not)
-        if (sizeof(T) == 8 && int8_layer(s, l) && s->use_i8_val && (int64_t)S.N * ng >= (int64_t)s->val_i8_min_tiles) {
+        if (sizeof(T) == 8 && int8_value_layer(s, l) && (int64_t)S.N * ng >= (int64_t)s->val_i8_min_tiles) {
             uint8_t* wp; double* sw;
             i8_prepare(s, l, (const double*)blk(s->i_wloc[l]), Kloc, Nout, st, &wp, &sw);
             const int ntiles = (int)(S.N * ng);
