@@ -575,7 +575,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                                        (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, blk(s->i_wloc[0]), K0loc, c.ZB, Nout, S.P, c.YO, c.MEAN[1]);
                 }
             } else if (int8_layer(s, l)) {
-                // dense residual layer of the 5-slot-tile float64 cells: the per-electron contraction as an error-free split on the
+                // dense residual layer of the 5-slot-tile float64 cells: the per-electron contraction as a 47-bit fixed-point split on the
                 // int8 matrix pipe (ds_i8.h); float64 in, float64 out, same shared term, same epilogue
                 uint8_t* wp; double* sw;
                 i8_prepare(s, l, (const double*)blk(s->i_wloc[l]), Kloc, Nout, st, &wp, &sw);
@@ -1486,8 +1486,8 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
                                  dev_desc.hidden_single, dev_desc.hidden_double, rs, rd))
             return rc;
     }
-    // only spin-down electrons: the reference drops the empty channel (network.py:113-117 filters `spins`), which leaves the network
-    // of the mirrored cell (n_dn, 0) with the same parameter tree -- run that
+    // only spin-down electrons: an extension beyond the reference (its parameter tree drops the empty channel, network.py:113-117, but
+    // its forward raises on it, network.py:537-553): the parameter tree is that of the mirrored cell (n_dn, 0) -- run that
     if (dev_desc.n_up == 0 && dev_desc.n_dn > 0) {
         dev_desc.n_up = dev_desc.n_dn;
         dev_desc.n_dn = 0;
@@ -1495,6 +1495,16 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
         dev_desc.klist_dn = nullptr;
     }
     if (dev_desc.n_up + dev_desc.n_dn < 1) return fail("n_up + n_dn must be >= 1");
+    if (rs[0]) {
+        // a first layer as wide as its input features carries the reference's residual (network.py:525); the residual kernels take
+        // their K rows in whole operand rings of 16, and K = input width + nch x (pair features padded to 4) is 64 k + 4 or + 8 for
+        // the 'nu' features and for 'tri' with one spin channel: refused HERE, not at the first launch
+        const int nf = ref_desc->distance_type == 0 ? 4 : 7, nch = dev_desc.n_dn > 0 ? 2 : 1;
+        const int k0 = rup(nf * ref_desc->n_atoms_prim, 4) + nch * rup(nf, 4);
+        if (k0 % 16)
+            return fail("hidden_single[0] = %d equals the width of the input features: the reference adds a residual there (network.py:525), "
+                        "which the kernels run only when the layer's %d per-electron input rows are a multiple of 16", ref_desc->hidden_single[0], k0);
+    }
     const ds_system_desc* desc = &dev_desc;
     if (int rc = check_arch(desc)) return rc;
     if (!desc->prim_atoms || !desc->klist_up || (desc->n_dn > 0 && !desc->klist_dn) || !desc->sim_atoms || !desc->sim_charges ||

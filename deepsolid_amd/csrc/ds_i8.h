@@ -2,7 +2,8 @@
 //
 //   Z[tile][n][slot] = sum_k W[k][n] X[tile][k][slot]      K = 64 NCH per-electron rows, 256 features, 80 jet slots (N = 24 ... 26)
 //
-// as an error-free split ("Ozaki scheme") on v_mfma_i32_16x16x64_i8 (16 cycles for 32768 operations; v_mfma_f64_16x16x4_f64 takes 64
+// as a 47-bit truncating fixed-point split (an "Ozaki scheme" with the low plane products dropped: NOT error-free, see `error` below)
+// on v_mfma_i32_16x16x64_i8 (16 cycles for 32768 operations; v_mfma_f64_16x16x4_f64 takes 64
 // cycles for 2048), float64 in, float64 out, the layer epilogue of ds_gemm.h (shared term, tanh chain rule on the jets, residual)
 // behind it:
 //

@@ -75,8 +75,10 @@ class DeviceSystem:
         prim = simulation_cell.original_cell
         self.nelec = tuple(int(n) for n in simulation_cell.nelec)
         if self.nelec[0] == 0 and self.nelec[1] > 0:
-            # only spin-down electrons: the reference drops the empty channel (network.py:113-117), which leaves the network of the
-            # mirrored cell (n_dn, 0) with the same parameter tree; the library does the same swap for a C caller
+            # only spin-down electrons -- an EXTENSION beyond the reference: its parameter tree drops the empty channel
+            # (network.py:113-117) but its forward then raises (network.py:537-553 pairs the empty block with orbital[0]).  The
+            # parameter tree is that of the mirrored cell (n_dn, 0), which is what runs here; the library does the same swap for a
+            # C caller.  Checked against this repo's oracle only, not against reference-executed numbers
             self.nelec = (self.nelec[1], 0)
             klist = (klist[1], klist[0])
         self.n = sum(self.nelec)

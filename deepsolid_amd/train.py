@@ -23,19 +23,23 @@ AuxiliaryLossData = namedtuple('AuxiliaryLossData', ['variance', 'local_energy',
 
 
 def clip_difference(diff, clip_local_energy, clip_type):
-    """train.py:105-129: clip E_L - E around the batch statistics (statistics pmean'd over ranks)."""
+    """train.py:105-129: clip E_L - E around the batch statistics (statistics pmean'd over ranks).
+
+    The two statistics of a clip type travel in ONE packed all-reduce (the reference sends two pmeans).  They are taken of
+    `diff = E_L - loss` with the ALREADY all-reduced loss, so they cannot ride on the energy statistics' message: a training step
+    is three collectives (energy statistics, clip statistics, packed gradient), an energy evaluation one."""
     if clip_local_energy <= 0.0:
         return diff
     if clip_type == 'complex':
         radius, phase = diff.abs(), torch.angle(diff)
-        radius_tv = constants.pmean_if_pmap(radius.std(unbiased=False))
-        radius_mean = constants.pmean_if_pmap(torch.quantile(radius, 0.5))
+        radius_tv, radius_mean = constants.pmean_packed(radius.std(unbiased=False), torch.quantile(radius, 0.5))
+        radius_tv, radius_mean = radius_tv.to(radius.dtype), radius_mean.to(radius.dtype)
         lo, hi = radius_mean - radius_tv * clip_local_energy, radius_mean + radius_tv * clip_local_energy
         clip_radius = torch.minimum(torch.maximum(radius, lo), hi)
         return torch.polar(clip_radius, phase)
     if clip_type == 'real':
-        tv_re = constants.pmean_if_pmap(diff.real.abs().mean())
-        tv_im = constants.pmean_if_pmap(diff.imag.abs().mean())
+        tv_re, tv_im = constants.pmean_packed(diff.real.abs().mean(), diff.imag.abs().mean())
+        tv_re, tv_im = tv_re.to(diff.real.dtype), tv_im.to(diff.real.dtype)
         re = torch.minimum(torch.maximum(diff.real, -clip_local_energy * tv_re), clip_local_energy * tv_re)
         im = torch.minimum(torch.maximum(diff.imag, -clip_local_energy * tv_im), clip_local_energy * tv_im)
         return torch.complex(re, im)

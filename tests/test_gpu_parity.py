@@ -368,9 +368,10 @@ def test_int8_split_hidden_layer_vs_float64_kernel(no_lowrank, monkeypatch):
 
 
 def test_spin_down_only_cell_runs_as_its_mirror_image():
-    """nelec = (0, n): the reference drops the empty spin channel (network.py:113-117), which leaves the network of the cell (n, 0)
-    with the same parameter tree; DeviceSystem and ds_system_create mirror the cell (round 5: `n_up >= 1` was a create-time
-    refusal).  log|psi|, phase and E_kin against the oracle run on the (0, n) cell itself."""
+    """nelec = (0, n): an EXTENSION beyond the reference -- its parameter tree drops the empty spin channel (network.py:113-117) but its
+    forward raises on the empty block (network.py:537-553), so there are no reference-executed numbers for this case.  The tree
+    is that of the cell (n, 0); DeviceSystem and ds_system_create mirror the cell.  log|psi|, phase and E_kin against this
+    repo's oracle run on the (0, n) cell itself."""
     from deepsolid_amd import hamiltonian, network, systems
     from oracle.testing import make_test_params
     cell, klist = systems.build('bcc_li', nelec=(0, 24))
