@@ -218,7 +218,7 @@ def cpu_baseline(cell, klist, net_kw, params_np, x_np, e_gpu, seconds=20.0, walk
         xb = torch.as_tensor(x_np[b])
         errs.append(abs(complex(e_gpu[b]) - (complex(ofl.stages(p, xb, klist, cell, net_kw)['ke']) + float(ew(xb)))))
     err2 = None
-    if e_gpu2 is not None:              # a second set of GPU energies (strict float64) against the same CPU evaluations
+    if e_gpu2 is not None:              # a second set of GPU energies (the opt-in int8 layer) against the same CPU evaluations
         e2 = [abs(complex(e_gpu2[0]) - (complex(ke_h[0]) + e_ew[0]))]
         if n_it == n3:
             e2 += [abs(complex(e_gpu2[b]) - (complex(ke_for[b]) + e_ew[b])) for b in range(min(nw, len(e_gpu2)))]
@@ -286,7 +286,8 @@ def main():
     ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-mcmc', action='store_true', help='skip the (untimed, reported separately) Metropolis sub-benchmark')
-    ap.add_argument('--no-strict', action='store_true', help='skip the strict-float64 (DS_NO_I8=1) timed region reported beside the headline')
+    ap.add_argument('--no-int8', '--no-strict', dest='no_int8', action='store_true',
+                    help='skip the timed region with the opt-in int8 hidden layer (DS_I8=1) reported beside the headline')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="process-group backend ('nccl' is RCCL on ROCm; 'gloo' only for the launcher test on CPU hosts)")
@@ -393,36 +394,48 @@ def main():
     prof_all = sysd.profile_read()
     sysd.profile(False)
     log(f'{args.steps} steps in {dt:.3f} s; kernels: ' + ', '.join(f'{k}={v[0]:.1f}ms' for k, v in prof_all.items()))
-    # the same step with every contraction in float64 arithmetic (DS_NO_I8=1 at handle creation: the dense hidden layer on
-    # k_jet_gemm<double,..,2> instead of the 47-bit int8 split), 5 timed steps on a handle of its own: the strict-float64 figure
-    # beside the headline, its energies checked against the same CPU evaluations below
-    strict = None
-    e_strict = None
-    if world == 1 and dtype == torch.float64 and sysd.int8_layers() and not args.no_strict:
-        os.environ['DS_NO_I8'] = '1'
+    # The same step with the dense hidden layer as the 47-bit int8 split of csrc/ds_i8.h (opt-in, DS_I8=1 at handle creation; the
+    # default and the headline are float64 arithmetic throughout since round 6), 5 timed steps on a handle of its own: reported
+    # beside the headline with its own error against the same CPU evaluations
+    i8blk = None
+    e_i8 = None
+    if world == 1 and dtype == torch.float64 and not sysd.int8_layers() and not args.no_int8:
+        os.environ['DS_I8'] = '1'
         try:
-            cell64, klist64 = systems.build(args.system)           # (a cell object of its own: handles are cached per cell)
-            net64 = network.make_solid_fermi_net(klist=klist64, simulation_cell=cell64, method_name='eval_logdet', dtype=dtype, **net_kw)
+            cell8, klist8 = systems.build(args.system)             # (a cell object of its own: handles are cached per cell)
+            net8 = network.make_solid_fermi_net(klist=klist8, simulation_cell=cell8, method_name='eval_logdet', dtype=dtype, **net_kw)
+            sys8 = net8.apply.system                               # (the handle is created on first use: inside the switch's scope)
         finally:
-            del os.environ['DS_NO_I8']
-        te64 = train.make_loss(net64.apply, None, cell64)
-        if net64.apply.system.int8_layers() == 0:
-            te64(params, x)
+            del os.environ['DS_I8']
+        te8 = train.make_loss(net8.apply, None, cell8)
+        if sys8.int8_layers() > 0:
+            te8(params, x)
             torch.cuda.synchronize()
-            n64 = 5
+            n8 = 5
+            sys8.profile(True, only='single_hidden')
             t0 = time.perf_counter()
-            for _ in range(n64):
-                loss64, aux64 = te64(params, x)
+            for _ in range(n8):
+                loss8, aux8 = te8(params, x)
             torch.cuda.synchronize()
-            dt64 = time.perf_counter() - t0
-            e_strict = aux64.local_energy[:64].cpu().numpy()
-            d_all = (aux64.local_energy - aux.local_energy).abs()
-            strict = {'value': args.batch * n64 / dt64, 'ms_per_step': dt64 / n64 * 1e3, 'steps': n64, 'max_abs_err_ha': None,
-                      'energy_mean_ha': float(loss64),
-                      'int8_vs_strict_max_abs_diff_ha': float(d_all.max()), 'int8_vs_strict_median_abs_diff_ha': float(d_all.median()),
-                      'note': 'DS_NO_I8=1: same chain, dense hidden layer as float64 MFMA; max_abs_err_ha against the same CPU evaluations as the headline'}
-            log(f"strict float64: {strict['ms_per_step']:.2f} ms per step, int8 vs strict max |dE_L| {strict['int8_vs_strict_max_abs_diff_ha']:.2e} Ha")
-        del te64, net64
+            dt8 = time.perf_counter() - t0
+            ms8, nl8 = sys8.profile_read()['single_hidden']
+            sys8.profile(False)
+            e_i8 = aux8.local_energy[:64].cpu().numpy()
+            d_all = (aux8.local_energy - aux.local_energy).abs()
+            n_e8 = sum(cell.nelec)
+            kloc8 = net_kw['hidden_dims'][0][0] + (2 if cell.nelec[1] else 1) * net_kw['hidden_dims'][0][1]
+            ops8 = 21 * 2.0 * kloc8 * net_kw['hidden_dims'][0][0] * ((3 * n_e8 + 2 + 15) // 16 * 16) * n_e8
+            ach8 = ops8 * args.batch * nl8 / max(ms8 * 1e-3, 1e-12) / 1e12
+            i8blk = {'value': args.batch * n8 / dt8, 'ms_per_step': dt8 / n8 * 1e3, 'steps': n8, 'max_abs_err_ha': None,
+                     'energy_mean_ha': float(loss8), 'int8_layers': sys8.int8_layers(),
+                     'int8_vs_float64_max_abs_diff_ha': float(d_all.max()), 'int8_vs_float64_median_abs_diff_ha': float(d_all.median()),
+                     'kernel': 'ds::i8::k_layer_i8<5,2>', 'avg_launch_ms': ms8 / max(nl8, 1),
+                     'roofline': {'bound': 'mfma', 'achieved': ach8, 'peak': PEAK_I8_TOPS, 'unit': 'TOP/s', 'frac': ach8 / PEAK_I8_TOPS,
+                                  'useful_frac': ach8 / PEAK_I8_TOPS * (3 * n_e8 + 2) / ((3 * n_e8 + 2 + 15) // 16 * 16),
+                                  'note': 'executed int8 operations (21 plane products, padded slots included) / launch time / (1024 SIMDs x 2048 op/clk x 2.4 GHz)'},
+                     'note': 'DS_I8=1: same chain, dense hidden layer as a 47-bit truncating int8 split (opt-in); max_abs_err_ha against the same CPU evaluations as the headline'}
+            log(f"int8 split (opt-in): {i8blk['ms_per_step']:.2f} ms per step, layer {i8blk['avg_launch_ms']:.2f} ms, max |dE_L| vs float64 {i8blk['int8_vs_float64_max_abs_diff_ha']:.2e} Ha")
+        del te8, net8
         torch.cuda.empty_cache()
     mcmc = None
     if not args.no_mcmc:
@@ -591,7 +604,8 @@ def main():
         # evidence of GPU work that does not depend on an smi sample: HIP-event time of the timed region and the kernel sum of a step
         'gpu_ms_timed_region': gpu_ms_main, 'kernel_ms_sum_per_step': sum(kms.values()),
         'mcmc': mcmc,
-        'strict_f64': strict,
+        # the default IS strict float64 since round 6; the opt-in int8 hidden layer beside it
+        'strict_f64': True, 'int8_split': i8blk,
     }
     if other:
         out['other_scaling'] = other
@@ -606,11 +620,11 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         params_np = {k: [{kk: vv.cpu().numpy() for kk, vv in d.items()} for d in v] for k, v in params.items()}
         cb, err = cpu_baseline(cell, klist, net_kw, params_np, x_np, aux.local_energy[:64].cpu().numpy(), args.cpu_seconds, system=args.system,
-                               e_gpu2=e_strict)
+                               e_gpu2=e_i8)
         out['cpu_baseline'] = cb
         out['max_abs_err_ha'] = float(err)
-        if strict is not None and getattr(cpu_baseline, 'err2', None) is not None:
-            strict['max_abs_err_ha'] = float(cpu_baseline.err2)
+        if i8blk is not None and getattr(cpu_baseline, 'err2', None) is not None:
+            i8blk['max_abs_err_ha'] = float(cpu_baseline.err2)
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out))

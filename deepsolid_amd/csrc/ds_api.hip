@@ -107,7 +107,7 @@ struct ds_system {
     bool use_i8_val = true;           // DS_NO_I8_VAL unset: the value chain's residual hidden layers run as the int8 split too (large batches)
     bool use_pair_fuse = true;        // DS_NO_PAIR_FUSE unset: a log-psi forward runs all pair layers in one launch (k_pair_stream_val, ds_value.h)
     bool use_ldsb = true;             // DS_NO_LDSB unset: float32 cells with more than 10 slot tiles run the orbital head with LDS-staged jet rows (ds_ldsb.h)
-    bool use_i8 = true;               // DS_NO_I8 unset: dense hidden layers of the 5-slot-tile float64 cells run their per-electron contraction as an int8 split (ds_i8.h)
+    bool use_i8 = false;              // DS_I8=1: dense hidden layers of the 5-slot-tile float64 cells run their per-electron contraction as a 47-bit int8 split (ds_i8.h); default since round 6: float64 MFMA (the split measured 17.0-17.7 ms against 19.6 at 13 x the energy error)
     void* i8_wp = nullptr;            // per layer: digit planes of its weights + (behind them) the 256 column scales; filled once per C-ABI call
     uint64_t call_seq = 0;            // counts the C-ABI calls that take `params` (the planes of layer l are current when i8_prepped[l] == call_seq)
     uint64_t i8_prepped[DS_MAX_LAYERS];   // (set to ~0 at creation: never equal to a call count)
@@ -431,7 +431,7 @@ inline bool int8_layer(const ds_system* s, int l) {
 inline bool int8_value_layer(const ds_system* s, int l) {
     const ds::SysDev<double>& S = s->sd;
     const int Kloc = S.h1[l] + S.nch * S.h2[l];
-    return s->dtype == 0 && s->use_i8 && s->use_i8_val && l >= 1 && s->res1[l] && ds::PV == ds::i8::P && S.h1[l + 1] == ds::i8::NOUT && Kloc == 320;
+    return s->dtype == 0 && s->use_i8_val && l >= 1 && s->res1[l] && ds::PV == ds::i8::P && S.h1[l + 1] == ds::i8::NOUT && Kloc == 320;
 }
 
 // digit planes + column scales of layer l's per-electron weights: prepared by the first launch of a C-ABI call that needs them (the
@@ -1564,7 +1564,7 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
     if (const char* e = getenv("DS_VAL_NB")) { const int v = atoi(e); s->val_nb = (v == 1 || v == 2 || v == 4) ? v : 0; }
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
-    s->use_i8 = getenv("DS_NO_I8") == nullptr;
+    s->use_i8 = getenv("DS_I8") != nullptr && getenv("DS_NO_I8") == nullptr;
     s->use_ldsb = getenv("DS_NO_LDSB") == nullptr;
     s->use_pair_fuse = getenv("DS_NO_PAIR_FUSE") == nullptr;
     s->use_i8_val = getenv("DS_NO_I8_VAL") == nullptr;

@@ -596,7 +596,7 @@ class DeviceSystem:
 
     def int8_layers(self):
         """Number of dense hidden layers per local-energy evaluation whose per-electron contraction runs as an int8 split
-        (csrc/ds_i8.h; 0 with DS_NO_I8=1 or for shapes without an instance)."""
+        (csrc/ds_i8.h; 0 unless the handle was created with DS_I8=1, or for shapes without an instance)."""
         return int(self.lib.ds_int8_layers(self.handle))
 
     def profile_clock(self):

@@ -124,9 +124,9 @@ int ds_system_create(const ds_system_desc* desc, ds_system** out);
 void ds_system_destroy(ds_system* sys);
 const char* ds_last_error(void);
 
-/* Number of dense hidden one-electron layers per local-energy evaluation whose per-electron contraction runs as an error-free
- * split on the int8 matrix pipe (csrc/ds_i8.h: float64 in, float64 out; 5-slot-tile float64 cells with 256 features).
- * 0 when the library was loaded with DS_NO_I8=1 or the architecture has no instance. */
+/* Number of dense hidden one-electron layers per local-energy evaluation whose per-electron contraction runs as a 47-bit
+ * truncating fixed-point split on the int8 matrix pipe (csrc/ds_i8.h: float64 in, float64 out; 5-slot-tile float64 cells with 256
+ * features).  Opt-in since round 6 (environment DS_I8=1 at ds_system_create): 0 otherwise, or when the architecture has no instance. */
 int ds_int8_layers(const ds_system* sys);
 
 int64_t ds_param_count(const ds_system* sys);

@@ -331,9 +331,9 @@ def test_lowrank_first_hidden_layer_vs_dense_path(name, monkeypatch):
 @pytest.mark.parametrize('no_lowrank', [False, True])
 def test_int8_split_hidden_layer_vs_float64_kernel(no_lowrank, monkeypatch):
     """The dense residual hidden layers of the 5-slot-tile float64 cells (bcc-Li 2x2x2: layer 2; with DS_NO_LOWRANK=1 layers 1 and 2)
-    run their per-electron contraction as an error-free split on the int8 matrix pipe (csrc/ds_i8.h: 47-bit fixed point under one
-    scale per 64-row column chunk, six int8 digit planes, 21 plane products, float64 recombination).  DS_NO_I8=1 (read at system
-    creation) restores k_jet_gemm<double,4,5,2>.  Both paths must reproduce the reference-executed kinetic energies at the same
+    can run their per-electron contraction as a truncating fixed-point split on the int8 matrix pipe (csrc/ds_i8.h: 47-bit fixed point under one
+    scale per 64-row column chunk, six int8 digit planes, 21 plane products, float64 recombination) when the library is asked to:
+    DS_I8=1, read at system creation (round 6: the default is k_jet_gemm<double,4,5,2> again).  Both paths must reproduce the reference-executed kinetic energies at the same
     1e-9 as everywhere, agree with each other to 5e-10 Ha (tools/i8split_accuracy.py: 4e-11 expected), and the layer output itself
     must agree to 1e-11 of its largest entry; a NaN coordinate must come out as NaN in that walker only."""
     from deepsolid_amd.device import DeviceSystem
@@ -347,12 +347,13 @@ def test_int8_split_hidden_layer_vs_float64_kernel(no_lowrank, monkeypatch):
     else:
         monkeypatch.delenv('DS_NO_LOWRANK', raising=False)
     out, g3 = {}, {}
-    for flag in (None, '1'):
+    for flag in (None, '1'):                       # None: the int8 split, '1': the float64 kernel
         if flag:
-            monkeypatch.setenv('DS_NO_I8', flag)
+            monkeypatch.delenv('DS_I8', raising=False)
         else:
-            monkeypatch.delenv('DS_NO_I8', raising=False)
+            monkeypatch.setenv('DS_I8', '1')
         sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
+        assert (sysd.int8_layers() > 0) == (flag is None)
         N, D, P, NP, A, nch, h1, h2, ldk = dims(sysd)
         out[flag] = torch.view_as_complex(sysd.local_energy(dp, x)[0]).cpu().numpy()
         g3[flag] = sysd.debug_stage(dp, x, 'g3', nw * N * ldk * P).cpu().numpy().reshape(nw, N, ldk, P)[:, :, :h1[3], :D]
@@ -410,7 +411,7 @@ def test_int8_split_layer_other_shapes_vs_oracle(nelec, hidden_dims, monkeypatch
     x64 = systems.synthetic_walkers(cell, 2, seed=10)
     x = torch.as_tensor(x64, device='cuda')
     ref = complex(ofl.stages(onet.params_to_torch(params), tt(x64[0]), klist, cell, net_kw)['ke'])
-    monkeypatch.delenv('DS_NO_I8', raising=False)
+    monkeypatch.setenv('DS_I8', '1')
     sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
     nch = 2 if nelec[1] else 1
     kloc = [h[0] + nch * h[1] for h in hidden_dims]
@@ -421,7 +422,7 @@ def test_int8_split_layer_other_shapes_vs_oracle(nelec, hidden_dims, monkeypatch
     assert sysd.int8_layers() == expect, (sysd.int8_layers(), expect)
     ke = torch.view_as_complex(sysd.local_energy(dp, x)[0]).cpu().numpy()
     assert abs(ke[0] - ref) < 1e-9 * max(1.0, abs(ref)), (ke[0], ref)
-    monkeypatch.setenv('DS_NO_I8', '1')
+    monkeypatch.delenv('DS_I8', raising=False)
     ke64 = torch.view_as_complex(DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64).local_energy(dp, x)[0]).cpu().numpy()
     assert np.abs(ke - ke64).max() < 5e-10 * max(1.0, np.abs(ke64).max())
 
@@ -718,8 +719,7 @@ def test_int8_split_value_chain_layers_vs_float64_kernels(name, n_syn, monkeypat
         np.testing.assert_allclose(la[:nfx], fx['logabs'][:nfx], atol=1e-9)
     np.testing.assert_allclose(out[0][0][ok], out[1][0][ok], rtol=2e-12, atol=1e-10)     # (|log psi| ~ 55 at 24, ~ 470 at 48 electrons)
     np.testing.assert_allclose(out[0][1][ok], out[1][1][ok], rtol=0, atol=1e-9)
-    if not os.environ.get('DS_NO_I8'):                               # (a suite run with DS_NO_I8=1 forced has no int8 kernel on either side)
-        assert not np.array_equal(out[0][0][ok], out[1][0][ok])      # the two paths really are different kernels
+    assert not np.array_equal(out[0][0][ok], out[1][0][ok])          # the two paths really are different kernels
 
 
 @pytest.mark.parametrize('nelec,hidden_dims,use_last', [((12, 12), ((64, 16),) * 4, False),                    # three fused pair layers, 16 wide

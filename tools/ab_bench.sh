@@ -5,7 +5,7 @@ VAR=$1; A=$2; B=$3; shift 3
 mkdir -p gpurun_out
 for v in "$A" "$B"; do
   if [ "$v" = default ]; then unset $VAR; else export $VAR=$v; fi
-  python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mcmc --no-strict "$@" 2>gpurun_out/ab_${VAR}_$v.err | tail -1 > gpurun_out/ab_${VAR}_$v.json
+  python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mcmc --no-int8 "$@" 2>gpurun_out/ab_${VAR}_$v.err | tail -1 > gpurun_out/ab_${VAR}_$v.json
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_${VAR}_$v.json"))

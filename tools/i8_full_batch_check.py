@@ -1,5 +1,5 @@
 """Round 5: the int8-split hidden layer against the float64 kernel on a FULL bench batch (4096 synthetic walkers, bcc-Li):
-distribution of |E_L(int8 path) - E_L(float64 path)| per walker.  Two systems in one process (DS_NO_I8 is read at creation)."""
+distribution of |E_L(int8 path) - E_L(float64 path)| per walker.  Two systems in one process (DS_I8 is read at creation)."""
 import json
 import os
 import sys
@@ -22,9 +22,9 @@ x = torch.as_tensor(systems.synthetic_walkers(cell, B, seed=1234), device='cuda'
 out = {}
 for flag in (None, '1'):
     if flag:
-        os.environ['DS_NO_I8'] = flag
+        os.environ.pop('DS_I8', None)
     else:
-        os.environ.pop('DS_NO_I8', None)
+        os.environ['DS_I8'] = '1'
     sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
     out[flag] = torch.view_as_complex(sysd.local_energy(params, x)[0]).cpu().numpy()
     assert (sysd.int8_layers() > 0) == (flag is None)

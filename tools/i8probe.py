@@ -92,7 +92,7 @@ def main():
                 bout[f'{threads}thr_order{order}'] = dict(ms=ms, ghz=float(ghz), cycles_per_mfma_per_simd=float(ms * 1e-3 * ghz * 1e9 / (n_mfma / 1024)))
         print(json.dumps({'i8_mfma_rate': out, 'burst_rate': bout}))
         return
-    os.environ['DS_NO_I8'] = '1'          # the library's own dense layer as the float64 kernel (the int8 layer is its default since round 5)
+    os.environ.pop('DS_I8', None)         # the library's own dense layer as the float64 kernel (its default again since round 6)
     from deepsolid_amd import network, systems, hamiltonian
     dev = torch.device('cuda', 0)
     cell, klist = systems.build('bcc_li')
