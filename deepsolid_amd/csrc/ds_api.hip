@@ -692,7 +692,12 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 if (n == 32) DS_TRS(4); else DS_TRS(6);        // 2n = 16 NT exactly
 #undef DS_TRS
             } else if (sw8) { if (nt <= 4) DS_TRM(4, 8, 4); else DS_TRM(6, 8, 4); }
-            else if (n == 12) DS_TRMF(2, 16, 4, 12); else if (n == 24) DS_TRMF(3, 16, 8, 24);      // (compile-time n: see the kernel)
+            else if (n == 12) {
+                // (pair table in LDS, one operand tile: 37.2 KB -- Y + the table -- and < 128 registers: four workgroups per CU)
+                const size_t tbytes = (size_t)n * 2 * n * 16 * sizeof(T) + 512;      // Y + the pair table (78 x 4 bytes)
+                hipLaunchKernelGGL((ds::k_det_trace_mfma<T, 2, 16, 4, 12>), dim3(S.K, (unsigned)Bc), dim3(256), tbytes, st, S, c.MOUT, L.MOUT, L.mout_off[sp], sp, c.MINV, L.MINV,
+                                   L.minv_off[sp], c.TR, L.TR, L.tr_off[sp], c.DETS, L.DETS, L.dets_off[sp], (s->dbg & 32) ? s->clk_dev + 2 : (unsigned long long*)nullptr);
+            } else if (n == 24) DS_TRMF(3, 16, 8, 24);      // (compile-time n: see the kernel)
             else if (nt == 1) DS_TRM(1, 16, 4); else if (nt == 2) DS_TRM(2, 16, 4); else if (nt == 3) DS_TRM(3, 16, 8); else if (nt == 4) DS_TRM(4, 16, 8);
             else DS_TRM(6, 16, 4);
 #undef DS_TRM

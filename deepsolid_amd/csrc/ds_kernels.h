@@ -660,12 +660,30 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
             poB[k] = (e * n2 + 2 * i) * SW + d;
         }
     }
+    // Compile-time even n below the register-table sizes (n = 12, the 24-electron benchmark cell): the (i, e) -> LDS offsets of the
+    // pair terms in a TABLE IN LDS (behind the reduction buffer), one broadcast read per term instead of a division and a remainder
+    // per term and tile; tr Y_d straight from the diagonal by one thread per slot -- no reduction buffer, one barrier less per tile
+    // (round 6: pairs 17 k -> ... of the 78 k cycles a workgroup lives, tools/trace_timeline.py)
+    constexpr bool TABP = NFIX > 0 && !FASTP && (NFIX % 2) == 0 && SW == 16;
+    constexpr int TNPAIR = TABP ? (NFIX / 2) * (NFIX + 1) : 1, TNPT = TABP ? (TNPAIR + NG - 1) / NG : 1;
+    unsigned* ptab = reinterpret_cast<unsigned*>(red);      // (table instances: the table sits where the per-tile reduction buffer would; the final
+                                                             //  reduction of y2 uses the then dead Y -- 37.2 KB per workgroup, four per CU)
+    if constexpr (TABP) {
+        for (int pi = tid; pi < TNPAIR; pi += NTHR) {
+            const int r = pi / (NFIX + 1), t = pi - r * (NFIX + 1);
+            const int i = t < NFIX - r ? r : NFIX - 1 - r, e = t < NFIX - r ? r + t : i + (t - (NFIX - r));
+            ptab[pi] = (unsigned)((i * n2 + 2 * e) * SW) | ((unsigned)((e * n2 + 2 * i) * SW) << 16);
+        }
+        // (visible to all waves behind the first tile's product barrier)
+    }
     if (stamp) c_setup = clock64() - c_begin;
     for (int sp = 0; sp < nsp; ++sp) {
         const int st = sp / (16 / SW), half = sp % (16 / SW);
         if (stamp) c_t = clock64();
         if (TILE_PF) {
-            load_tile(nxt, sp + 1);
+            // (table instances: no second operand tile -- the next tile's rows are requested into `cur` itself right behind this tile's
+            //  products, with the pair sums and two barriers as cover: 48 registers less, a fourth workgroup per CU)
+            if constexpr (!TABP) load_tile(nxt, sp + 1);
 #pragma unroll
             for (int rr = 0; rr < RW; ++rr) {
                 const int i = wave + NW * rr;
@@ -687,6 +705,7 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
                         if (np < n2) Y[((size_t)i * n2 + np) * SW + lr] = acc[nt][r];
                     }
             }
+            if constexpr (TABP) load_tile(cur, sp + 1);
         } else
         for (int i = wave; i < n; i += NW, ++q) {
             load_q(bm, q + 2);
@@ -744,6 +763,29 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
             }
             continue;
         }
+        if constexpr (TABP) {
+#pragma unroll
+            for (int k = 0; k < TNPT; ++k) {
+                const int pi = g + NG * k;
+                if (pi < TNPAIR && slot >= 2) {
+                    const unsigned ent = ptab[pi];
+                    const int oa = (int)(ent & 0xffffu) + d, ob = (int)(ent >> 16) + d;
+                    const Cx<T> yie(Y[oa], Y[oa + SW]), yei(Y[ob], Y[ob + SW]);
+                    y2 = cx_fma((oa == ob ? T(1) : T(2)) * yie, yei, y2);
+                }
+            }
+            if (g == NG - 1 && live) {      // (the last group has the fewest pair terms)
+                Cx<T> t(0, 0);
+#pragma unroll
+                for (int i = 0; i < (NFIX > 0 ? NFIX : 1); ++i) t = t + Cx<T>(Y[((size_t)i * n2 + 2 * i) * SW + d], Y[((size_t)i * n2 + 2 * i + 1) * SW + d]);
+                Tw[slot] = t.re;
+                Tw[P + slot] = t.im;
+            }
+            if (stamp) { const long long c = clock64(); c_pairs += c - c_t; c_t = c; }
+            __syncthreads();
+            if (stamp) { const long long c = clock64(); c_bar2 += c - c_t; c_t = c; }
+            continue;
+        }
         Cx<T> trc(0, 0);
         // sum_{i,e} Y[i][e] Y[e][i] = sum_i Y[i][i]^2 + 2 sum_{i<e} Y[i][e] Y[e][i]: upper triangle only.  Rows r and
         // n-1-r together hold n+1 entries (n even); odd n walks the full square.
@@ -787,11 +829,12 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
         unsigned long long* o = tl + wave * 8;
         o[0] = c_setup; o[1] = c_prod; o[2] = c_bar1; o[3] = c_pairs; o[4] = c_bar2; o[5] = c_red; o[6] = clock64() - c_begin; o[7] = 0;
     }
-    red[tid] = y2;
+    Cx<T>* fred = TABP ? reinterpret_cast<Cx<T>*>(Y) : red;      // (the last tile's barrier has passed: Y is dead)
+    fred[tid] = y2;
     __syncthreads();
     if (tid == 0) {
         Cx<T> t(0, 0);
-        for (int u = 0; u < NTHR; ++u) t = t + red[u];
+        for (int u = 0; u < NTHR; ++u) t = t + fred[u];
         T* dw = DETS + (size_t)w * dets_stride + dets_off + (size_t)kdet * 4;
         dw[2] = t.re;
         dw[3] = t.im;
