@@ -946,8 +946,8 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
                                vb.MINV, L.MOUT, L.mout_off[sp], DETS, dstride, s->ws.dets_off[sp], PV, PV, PV, PV);
         }
         if (out_logabs || out_phase)
-            hipLaunchKernelGGL((ds::k_combine<T>), dim3((unsigned)Bc), dim3(64), 0, st, S, (const T*)nullptr, (size_t)0, (size_t)0, DETS, dstride,
-                               s->ws.dets_off[1], (T*)nullptr, out_logabs, out_phase, (T*)nullptr);
+            hipLaunchKernelGGL((ds::k_combine_val<T>), dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, S, DETS, dstride, s->ws.dets_off[1], (long)Bc,
+                               out_logabs, out_phase);
     }
     HIP_OK(hipGetLastError());
     return 0;
