@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
 // the layer output itself is not needed (last pair layer of a log-psi forward).
 constexpr int PM_SLOTS = 3;
 template <typename T, int NT2, bool RES, bool VAL>
-__global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __restrict__ Hin, int Kin, const T* __restrict__ W,
+__global__ void __launch_bounds__(256, ((RES && !VAL && sizeof(T) == 8 && NT2 == 2) ? 2 : 3)) k_two_layer(SysDev<T> S, const T* __restrict__ Hin, int Kin, const T* __restrict__ W,
                                                    const T* __restrict__ bias, T* __restrict__ Hout, T* __restrict__ PARTM = nullptr) {
     typedef typename Acc4<T>::type acc_t;
     const int w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -278,6 +278,28 @@ __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __re
     for (int a = 0; a < NT2; ++a)
 #pragma unroll
         for (int c = 0; c < 5; ++c) acc[a][c] = acc_t{0, 0, 0, 0};
+    // float64 residual layers of the energy chain (Kin == Kout): the residual H[n][c][pair] of accumulator element (a, c, r) -- row
+    // n = 16 a + lq + 4 r -- IS the B operand this very lane loads at k-step n / 4 = 4 a + r (operand row n % 4 = lq): all 4 NT2 k-steps'
+    // operands are requested up front and kept (5 x 4 NT2 numbers), the epilogue reads no H a second time (6.0 -> 3.0 GB per launch,
+    // profiles/r05_pmc_traffic.json).  (float32: the accumulator row map 4 lq + r puts that operand into another lane.)
+    constexpr bool KEEP = RES && !VAL && sizeof(T) == 8;
+    T bk[KEEP ? 4 * NT2 : 1][5];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int ks = 0; ks < 4 * NT2; ++ks)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) bk[ks][c] = Hw[(size_t)((4 * ks + lq) * 5 + c) * NP];
+#pragma unroll
+        for (int ks = 0; ks < 4 * NT2; ++ks) {
+            T av[NT2];
+#pragma unroll
+            for (int a = 0; a < NT2; ++a) av[a] = W[(size_t)(4 * ks + lq) * Kout + 16 * a + lr];
+#pragma unroll
+            for (int a = 0; a < NT2; ++a)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) acc[a][c] = mfma16(av[a], bk[ks][c], acc[a][c]);
+        }
+    } else
     for (int ks = 0; ks < Kin / 4; ++ks) {
         T av[NT2], bv[5];
 #pragma unroll
@@ -318,7 +340,7 @@ __global__ void __launch_bounds__(256, 3) k_two_layer(SysDev<T> S, const T* __re
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
                 T v = o[c];
-                if (RES) v = (Hw[(size_t)(n * 5 + c) * NP] + v) * rs2;
+                if (RES) v = ((KEEP ? bk[KEEP ? 4 * a + r : 0][c] : Hw[(size_t)(n * 5 + c) * NP]) + v) * rs2;
                 if (Hout) Ho[(size_t)(n * 5 + c) * NP] = v;
                 if (VAL && PARTM) {
                     // running sum over the tile's pairs; the last lane of every (electron, spin) segment keeps its prefix:
