@@ -66,8 +66,9 @@ def _to_numpy(a):
     return np.asarray(a)
 
 
-def save(save_path, t, data, params, opt_state, mcmc_width, add_device_axis=True):
-    """checkpoint.py:94-124.  Tensors are converted to numpy; with ``add_device_axis`` every array gets the
+def save(save_path, t, data, params, opt_state, mcmc_width, add_device_axis=True, prefix='qmcjax_ckpt_'):
+    """checkpoint.py:94-124.  `prefix`: file name stem; anything but the default is NOT picked up by `find_last_checkpoint`
+    (the training driver's post-mortem state of an aborted run).  Tensors are converted to numpy; with ``add_device_axis`` every array gets the
     leading (1, ...) axis the reference expects from its pmap-replicated state."""
     lead = (lambda a: a if a is None or isinstance(a, (int, float)) else _to_numpy(a)[None]) if add_device_axis else _to_numpy
     # the scalar bypass above is for the optimiser state only (Adam's python step count).  mcmc_width ALWAYS gets the device
@@ -75,7 +76,7 @@ def save(save_path, t, data, params, opt_state, mcmc_width, add_device_axis=True
     # constants.py:29), which needs shape (n_devices,) -- a python float from the training driver included
     # (a scalar of any kind -> shape (1,); an array that already has the device axis is kept)
     width = (lambda a: np.asarray(_to_numpy(a), dtype=np.float64).reshape(-1)) if add_device_axis else _to_numpy
-    ckpt_filename = os.path.join(save_path, f'qmcjax_ckpt_{t:06d}.npz')
+    ckpt_filename = os.path.join(save_path, f'{prefix}{t:06d}.npz')
     with open(ckpt_filename, 'wb') as f:
         np.savez(f, t=t, data=lead(data), params=_map(params, lead),
                  opt_state=None if opt_state is None else _map(opt_state, lead),

@@ -1554,10 +1554,6 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
         int devid = 0;
         if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.multiProcessorCount > 0)
             s->n_cu = prop.multiProcessorCount;
-        if (hipMalloc(&s->i8_wp, (size_t)DS_MAX_LAYERS * (ds::i8::wp_bytes(64 * 5) + ds::i8::NOUT * sizeof(double))) != hipSuccess) {
-            ds_system_destroy(s);
-            return fail("hipMalloc of the int8 layer's weight planes failed");
-        }
     }
     if (hipMalloc((void**)&s->clk_dev, 1024 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(s->clk_dev, 0, 1024 * sizeof(unsigned long long)) != hipSuccess) {
@@ -1578,6 +1574,15 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
     if (const char* e = getenv("DS_DBG")) s->dbg = atoi(e);
     s->use_wide = getenv("DS_NO_WIDE") == nullptr;
     s->wide_all = getenv("DS_WIDE_ALL") != nullptr;
+    {
+        // digit planes of the int8 layers' weights: only for a handle some layer of which can run as an int8 split
+        bool need = false;
+        for (int l = 1; l < s->sd.n_layers; ++l) need = need || int8_layer(s, l) || int8_value_layer(s, l);
+        if (need && hipMalloc(&s->i8_wp, (size_t)DS_MAX_LAYERS * (ds::i8::wp_bytes(64 * 5) + ds::i8::NOUT * sizeof(double))) != hipSuccess) {
+            ds_system_destroy(s);
+            return fail("hipMalloc of the int8 layer's weight planes failed");
+        }
+    }
     // (grid.y carries the walker index: at most 65535 walkers per launch)
     if (const char* e = getenv("DS_CHUNK_WALKERS")) s->chunk_cap = std::min<int64_t>(65535, std::max<int64_t>(1, atol(e)));
     *out = s;

@@ -123,8 +123,9 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
     parameters and optimiser state keep their values, no CSV row is written for it (process.py:344), `rows` gets
     ``{'step': t, 'rejected': True, 'pmove': ...}`` and a warning is logged like the reference's (process.py:316).  A walker with a
     non-finite coordinate or non-finite parameters can never recover (the move is never accepted, the step never kept), so
-    after `max_rejected` (default 20) rejections IN A ROW the loop writes a checkpoint of the last good state (walkers, parameters,
-    optimiser state: nothing of a rejected step was kept) and raises instead of running to the end doing nothing;
+    after `max_rejected` (default 20) rejections IN A ROW the loop writes the state it is stuck in (walkers, parameters, optimiser
+    state: nothing of a rejected step was kept) as `aborted_ckpt_<t>.npz` -- a name `find_last_checkpoint` does not pick up, so a
+    restart resumes from the last regular checkpoint -- and raises instead of running to the end doing nothing;
     `max_rejected=None` is the reference's behaviour: log and go on (process.py:303-318)."""
     from . import checkpoint
     gen = _rank_generator(key, data.device, t_init)
@@ -157,7 +158,9 @@ def run_training(slog_net, logdet_net, params, data, simulation_cell, iterations
                 logging.warning('step %d: non-finite local energy / loss / gradient, step discarded (%d in a row)', t, n_rejected)
                 if max_rejected is not None and n_rejected >= max_rejected:
                     if save_path:
-                        checkpoint.save(save_path, t, data, params, opt_state, width)
+                        # post-mortem state under a name of its own: a restart must not resume from it (the walkers or parameters
+                        # that made every step fail are IN it), and it is the state from before the first rejected step, not step t's
+                        checkpoint.save(save_path, t, data, params, opt_state, width, prefix='aborted_ckpt_')
                     raise FloatingPointError(f'{n_rejected} consecutive training steps were rejected for non-finite values '
                                              f'(last at step {t}): walkers or parameters are not finite')
             else:
