@@ -514,7 +514,9 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         const int hin = hi;                                // the layer reads the pair stream of its own level (hi flips below)
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
         const bool res = s->res1[l];
-        if (res && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
+        // a first layer as wide as its input features: the residual is added by k_layer_res_add behind the layer (see there)
+        const bool res_sep = res && l == 0 && (Kloc % 16 != 0 || S.nf * S.A != Nout);
+        if (res && !res_sep && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         {
             dim3 block; unsigned gz;
             gemm_geom(Nout, NB, &block, &gz, ST);
@@ -583,12 +585,15 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 const dim3 igrid((unsigned)std::min<int64_t>(ntiles, s->n_cu));
                 hipLaunchKernelGGL((ds::i8::k_layer_i8<5, 2>), igrid, dim3(512), ds::i8::lds_bytes(), st, (const double*)c.G[gi], gts, (const uint4*)wp,
                                    (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
-            } else if (res) {
+            } else if (res && !res_sep) {
                 ga.oe.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }
                 layer_gemm(2, ga);
-            } else
+            } else {
                 layer_gemm(1, ga);
+                if (res_sep)
+                    hipLaunchKernelGGL((ds::k_layer_res_add<T>), dim3(S.N, (unsigned)Bc), dim3(256), 0, st, Xin, xws, xts, c.G[gi ^ 1], gws, gts, S.nf * S.A, Nout, S.P);
+            }
             }
         }
         gi ^= 1;
@@ -829,7 +834,8 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
         }
         if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
-        if (s->res1[l] && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
+        const bool res_sep = s->res1[l] && l == 0 && (Kloc % 16 != 0 || S.nf * S.A != Nout);      // (see run_chain)
+        if (s->res1[l] && !res_sep && Kloc % 16) return fail("residual layer with K = %d: the GEMM's operand ring needs K %% 16 == 0", Kloc);
         dim3 block; unsigned gz;
         gemm_geom(Nout, 4, &block, &gz);
         // (a float32 MFMA lasts half as long: the same rule on half the count -- diamond, 1024 walkers: forward 3.46 -> 3.40 ms)
@@ -868,12 +874,15 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
             const int ntiles = (int)(S.N * ng);
             hipLaunchKernelGGL((ds::i8::k_layer_i8<5, 4>), dim3((unsigned)std::min<int64_t>(ntiles, s->n_cu)), dim3(512), ds::i8::lds_bytes(), st, (const double*)Gin, gts,
                                (const uint4*)wp, (const double*)sw, (const double*)ZB, S.N, (double*)Gout, ntiles);
-        } else if (s->res1[l]) {
+        } else if (s->res1[l] && !res_sep) {
             if (nbh == 4) DS_VHID(4) else if (nbh == 2) DS_VHID(2) else DS_VHID(1)
-        } else
+        } else {
 #undef DS_VHID
             hipLaunchKernelGGL((ds::k_jet_gemm<T, 4, 5, 3>), dim3(S.N, (unsigned)ng, gz), block, 0, st, Gin, gws, gts, blk(s->i_wloc[l]), Kloc,
                                (const T*)nullptr, (size_t)0, (const T*)nullptr, 0, S.N, Gout, gws, gts, Nout, PV, ZB, blk(s->i_b[l]), ds::OrbEpi<T>{});
+            if (res_sep)
+                hipLaunchKernelGGL((ds::k_layer_res_add<T>), dim3(S.N, (unsigned)ng), dim3(256), 0, st, (const T*)Gin, gws, gts, Gout, gws, gts, S.nf * S.A, Nout, PV);
+        }
     }
     T* Gl = vb.Gl[S.n_layers];
     const int Kl = S.h1[S.n_layers], K2l = S.h2[S.n_layers];
@@ -1426,9 +1435,6 @@ int plan_widths(const int32_t* hs, const int32_t* hd, int n_layers, int n_in_sin
         rs[l] = a == (l == 0 ? n_in_single : hs[l - 1]);
         rd[l] = l < n_double && b == (l == 0 ? n_in_double : hd[l - 1]);
     }
-    if (rs[0] && n_in_single % 64)
-        return fail("hidden_single[0] = %d equals the width of the input features: the reference adds a residual there (network.py:525), "
-                    "which the kernels run only for input widths that are multiples of 64", hs[0]);
     if (rd[0])
         return fail("hidden_double[0] = %d equals the width of the pair features: the reference adds a residual there (network.py:527), "
                     "which the pair kernels do not run", hd[0]);
@@ -1500,16 +1506,6 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
         dev_desc.klist_dn = nullptr;
     }
     if (dev_desc.n_up + dev_desc.n_dn < 1) return fail("n_up + n_dn must be >= 1");
-    if (rs[0]) {
-        // a first layer as wide as its input features carries the reference's residual (network.py:525); the residual kernels take
-        // their K rows in whole operand rings of 16, and K = input width + nch x (pair features padded to 4) is 64 k + 4 or + 8 for
-        // the 'nu' features and for 'tri' with one spin channel: refused HERE, not at the first launch
-        const int nf = ref_desc->distance_type == 0 ? 4 : 7, nch = dev_desc.n_dn > 0 ? 2 : 1;
-        const int k0 = rup(nf * ref_desc->n_atoms_prim, 4) + nch * rup(nf, 4);
-        if (k0 % 16)
-            return fail("hidden_single[0] = %d equals the width of the input features: the reference adds a residual there (network.py:525), "
-                        "which the kernels run only when the layer's %d per-electron input rows are a multiple of 16", ref_desc->hidden_single[0], k0);
-    }
     const ds_system_desc* desc = &dev_desc;
     if (int rc = check_arch(desc)) return rc;
     if (!desc->prim_atoms || !desc->klist_up || (desc->n_dn > 0 && !desc->klist_dn) || !desc->sim_atoms || !desc->sim_charges ||

@@ -252,6 +252,24 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
     }
 }
 
+// Residual of a FIRST layer as wide as its input features (network.py:525: hidden_single[0] == nf x atoms; round 6).  The residual
+// kernels take the residual rows from the operand ring (K % 16 == 0, as many residual rows as device features); the layer-0 input has
+// K = features + pair-mean rows (64 k + 4 or + 8) and -- for widths that are not multiples of 64 -- fewer feature rows than the
+// zero-padded layer has outputs.  So layer 0 runs WITHOUT its residual (EPI 1 / 3) and this kernel finishes it in place:
+//   out[tile][n][:] = ((n < n_res ? in[tile][n][:] : 0) + out[tile][n][:]) / sqrt 2,   n < Nout
+// (a rare architecture: bandwidth-bound, one extra pass over the layer's output).  grid (tiles, walkers | groups), block 256.
+template <typename T>
+__global__ void __launch_bounds__(256) k_layer_res_add(const T* __restrict__ Xin, size_t x_ws, size_t x_ts, T* __restrict__ Gout, size_t g_ws,
+                                                       size_t g_ts, int n_res, int Nout, int P) {
+    const T* xi = Xin + (size_t)blockIdx.y * x_ws + (size_t)blockIdx.x * x_ts;
+    T* go = Gout + (size_t)blockIdx.y * g_ws + (size_t)blockIdx.x * g_ts;
+    const T rs2 = T(0.70710678118654752440);
+    for (int idx = threadIdx.x; idx < Nout * P; idx += blockDim.x) {
+        const T r = idx < n_res * P ? xi[idx] : T(0);
+        go[idx] = (r + go[idx]) * rs2;
+    }
+}
+
 // =====================================================================================
 // 2b. two-electron stream layer  h2 <- res(h2, tanh(h2 W + b))   (network.py:525-528)
 //     MFMA, C[n][(c,pair)] ; the five jet components of a pair sit in five accumulator tiles of the

@@ -194,6 +194,32 @@ def test_hidden_widths_without_kernel_instances(hidden_dims, use_last):
     assert_tree_close(grads, g_ref, 1e-7)
 
 
+@pytest.mark.parametrize('system,hidden_dims', [('lih', ((8, 16), (64, 16), (64, 16))),        # two atoms, 'nu': 8 input features = hidden_single[0]
+                                                ('bcc_li', ((4, 16), (4, 16), (64, 16)))])     # one atom: 4; layers 0 AND 1 residual at width 4
+def test_first_layer_as_wide_as_its_input_features(system, hidden_dims):
+    """hidden_single[0] == nf x atoms: the reference adds a residual at the FIRST layer (network.py:525-528).  Refused until round 6
+    (its K = features + pair-mean rows is 64 k + 4 / + 8, and a width like 8 pads to 64 device features of which only 8 have a
+    residual); now layer 0 runs without its residual and csrc/ds_kernels.h::k_layer_res_add finishes it.  Loss, local energies and
+    the energy gradient -- energy chain, value chain and reverse sweep -- against the oracle."""
+    from deepsolid_amd import network as dnet, train as dtrain
+    from oracle.testing import make_test_params
+    cell, klist = systems.build(system, **({'nelec': (3, 2)} if system == 'bcc_li' else {}))
+    net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=hidden_dims)
+    params = make_test_params(29, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    net = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    assert net.apply.system.residuals[0][0] is True
+    loss_fn = dtrain.make_loss(net.apply, None, cell, clip_local_energy=5.0, clip_type='real')
+    dp = dev_params(params)
+    xn = systems.synthetic_walkers(cell, 5, seed=23)
+    (loss, aux), grads = loss_fn.value_and_grad(dp, torch.as_tensor(xn, device='cuda'))
+    onet_ = oracle_net(cell, klist, net_kw, 'eval_logdet')
+    oloss = otrain.make_loss(onet_.apply, cell, mode='hessian', clip_local_energy=5.0, clip_type='real')
+    (l_ref, aux_ref), g_ref = oloss.value_and_grad(params, torch.as_tensor(xn))
+    assert abs(float(loss) - float(l_ref)) < 1e-8
+    assert float((aux.local_energy.cpu() - aux_ref.local_energy).abs().max()) < 1e-8
+    assert_tree_close(grads, g_ref, 1e-7)
+
+
 def test_forty_determinants():
     """More than 32 determinants (the reference has no bound; the library's is 64 since round 4): loss, local energies and energy
     gradient of a 40-determinant LiH wave function against the oracle."""
