@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""End-to-end check of the training loop on the benchmark cell with every round-5 kernel engaged (4096 bcc-Li walkers: fused pair
-stream, int8 value layers, int8 energy layer, low-rank layer): a few Adam iterations through inference.run_training, once with the
-defaults and once with the float64 / layer-by-layer sides forced; the energies of the two runs must agree to round-off of the
+"""End-to-end check of the training loop on the benchmark cell (4096 bcc-Li walkers: fused pair stream, int8 value layers, low-rank
+layer; with DS_I8=1 also the opt-in int8 energy layer): a few Adam iterations through inference.run_training, with the defaults,
+with the int8 energy layer switched on, and with the float64 / layer-by-layer sides forced; the energies of the two runs must agree to round-off of the
 sampler's decisions (same seeds; a decision can flip only on a ~1e-12 tie).    python tools/train_e2e_check.py [iterations]"""
 import os
 import subprocess
@@ -39,7 +39,9 @@ def run(env_extra, iters):
 if __name__ == '__main__':
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     a = run({}, iters)
-    b = run({'DS_NO_I8': '1', 'DS_NO_I8_VAL': '1', 'DS_NO_PAIR_FUSE': '1', 'DS_NO_LOWRANK': '1'}, iters)
-    for ra, rb in zip(a, b):
+    c = run({'DS_I8': '1'}, iters)
+    b = run({'DS_NO_I8_VAL': '1', 'DS_NO_PAIR_FUSE': '1', 'DS_NO_LOWRANK': '1'}, iters)
+    for ra, rc, rb in zip(a, c, b):
         print('default  ', ra)
+        print('DS_I8=1  ', rc)
         print('reference', rb)
