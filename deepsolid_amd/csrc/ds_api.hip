@@ -502,13 +502,18 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
             if (K2 % 4) return fail("pair-stream width %d is not a multiple of 4", K2);
             dim3 grid((S.NP / 16 + 3) / 4, (unsigned)Bc);
-            const bool res = s->res2[l];
+            // (a first pair layer as wide as the pair features: its residual is added by k_pair_res_add behind the layer)
+            const bool res_sep = s->res2[l] && l == 0;
+            const bool res = s->res2[l] && !res_sep;
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
             ProfScope ps(s, DS_PROF_TWO_LAYER, st);
 #define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, false>), grid, dim3(256), 0, st, S, c.H2[hi], K2, W2, b2, c.H2[hi ^ 1])
             if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
             else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
 #undef DS_TWO
+            if (res_sep)
+                hipLaunchKernelGGL((ds::k_pair_res_add<T>), dim3((unsigned)(((size_t)K2o * 5 * S.NP + 255) / 256), (unsigned)Bc), dim3(256), 0, st, c.H2[hi], K2, c.H2[hi ^ 1], K2o,
+                                   S.nf, S.NP);
         }
         // one-electron stream layer: GEMM over the N electron tiles + the shared spin-mean tile, then epilogue
         const int hin = hi;                                // the layer reads the pair stream of its own level (hi flips below)
@@ -789,7 +794,8 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
     hipLaunchKernelGGL((ds::k_features_val<T, 1>), dim3((unsigned)ng, fsplit), dim3(256), 0, st, S, x, (long)Bc, blk(s->i_pi[0]),
                        blk(s->i_sg[0]), blk(s->i_pi[S.nch - 1]), blk(s->i_sg[S.nch - 1]), vb.Gl[0], vb.MEAN0, vb.H2l[0], Q);
     const size_t gws = (size_t)S.N * S.ldk * PV, gts = (size_t)S.ldk * PV;
-    const bool fuse_means = S.n_up >= 8 && (S.n_dn >= 8 || S.n_dn == 0);
+    // (a first pair layer with a residual -- added behind the layer by k_pair_res_add -- has no segment sums of its final output)
+    const bool fuse_means = S.n_up >= 8 && (S.n_dn >= 8 || S.n_dn == 0) && !(S.n_double >= 1 && s->res2[0]);
     // log psi only: every pair layer in one launch, activations in registers (k_pair_stream_val).  Needs equal pair widths with a
     // kernel instance, no residual on the first pair layer (its input has another width anyway) and the segment sums as the only
     // consumer of the pair stream.  The sums of layer l go to PARTM (l = 0) and into the second H2 buffer, which this path leaves
@@ -821,7 +827,8 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
             const int K2o = S.h2[l + 1];
             if (K2o != 32 && K2o != 16) return fail("hidden_double must be 16 or 32 (got %d)", K2o);
             dim3 grid((S.NP / 16 + 3) / 4, (unsigned)(ng * (PV / 5)));
-            const bool res = s->res2[l];
+            const bool res_sep = s->res2[l] && l == 0;
+            const bool res = s->res2[l] && !res_sep;
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
             // the last pair layer's output is only needed as means unless the activations are kept (gradient pass) or the
             // orbital head / a later layer reads H2 again without a pair layer in between
@@ -831,6 +838,9 @@ int run_value_chain(ds_system* s, const T* params, const T* x, int64_t Bc, const
             if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
             else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
 #undef DS_TWO
+            if (res_sep)
+                hipLaunchKernelGGL((ds::k_pair_res_add<T>), dim3((unsigned)(((size_t)K2o * 5 * S.NP + 255) / 256), (unsigned)(ng * (PV / 5))), dim3(256), 0, st, Hin, K2, Hnext, K2o,
+                                   S.nf, S.NP);
         }
         if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
         const int Kloc = Kh + S.nch * K2, Ksh = S.nch * Kh;
@@ -1275,8 +1285,12 @@ int logpsi_vjp_impl(ds_system* s, const void* params_, const void* x_, int64_t B
                 const T* W2 = blk(s->i_w2[l]);
                 T* HBn = H2BAR[h2i]; T* HBi = H2BAR[h2i ^ 1];
 #define DS_TWOB(NTI, NTO, RES, DX) hipLaunchKernelGGL((ds::k_two_bwd<T, NTI, NTO, RES, DX>), pgrid, dim3(256), 0, st, S, HBn, vb.H2l[l + 1], \
-                                                      vb.H2l[l], W2, GBAR, Kpad, Kh, Z2BAR, HBi)
-                if (!dx) { if (K2o == 32) DS_TWOB(1, 2, false, false); else DS_TWOB(1, 1, false, false); }
+                                                      vb.H2l[l], W2, GBAR, Kpad, Kh, Z2BAR, HBi, K2)
+                if (!dx) {
+                    // (the first pair layer: no cotangent of its input; with the reference's residual there tanh(z) = sqrt 2 out - in)
+                    if (K2o == 32) { if (res2) DS_TWOB(1, 2, true, false); else DS_TWOB(1, 2, false, false); }
+                    else { if (res2) DS_TWOB(1, 1, true, false); else DS_TWOB(1, 1, false, false); }
+                }
                 else if (K2 == 32 && K2o == 32) { if (res2) DS_TWOB(2, 2, true, true); else DS_TWOB(2, 2, false, true); }
                 else if (K2 == 16 && K2o == 16) { if (res2) DS_TWOB(1, 1, true, true); else DS_TWOB(1, 1, false, true); }
                 else if (K2 == 32 && K2o == 16) DS_TWOB(2, 1, false, true);
@@ -1435,9 +1449,6 @@ int plan_widths(const int32_t* hs, const int32_t* hd, int n_layers, int n_in_sin
         rs[l] = a == (l == 0 ? n_in_single : hs[l - 1]);
         rd[l] = l < n_double && b == (l == 0 ? n_in_double : hd[l - 1]);
     }
-    if (rd[0])
-        return fail("hidden_double[0] = %d equals the width of the pair features: the reference adds a residual there (network.py:527), "
-                    "which the pair kernels do not run", hd[0]);
     return 0;
 }
 

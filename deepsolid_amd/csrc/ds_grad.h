@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(256) k_pair_scatter(SysDev<T> S, const T* __re
 template <typename T, int NTI, int NTO, bool RES, bool DX>
 __global__ void __launch_bounds__(256, 3) k_two_bwd(SysDev<T> S, const T* __restrict__ HBn, const T* __restrict__ Hout,
                                                  const T* __restrict__ Hin, const T* __restrict__ W, const T* __restrict__ GB, int ldg,
-                                                 int row0, T* __restrict__ Z2BAR, T* __restrict__ HBi) {
+                                                 int row0, T* __restrict__ Z2BAR, T* __restrict__ HBi, int kin_rows) {
     typedef typename Acc4<T>::type acc_t;
     constexpr int Kin = 16 * NTI, Kout = 16 * NTO;
     const int w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -376,7 +376,9 @@ __global__ void __launch_bounds__(256, 3) k_two_bwd(SysDev<T> S, const T* __rest
     if (pt * 16 >= NP) return;
     const int lr = lane & 15, lq = lane >> 4, q = pt * 16 + lr;
     const T rs2 = T(0.70710678118654752440), s2 = T(1.41421356237309504880);
-    const size_t ob = (size_t)w * Kout * 5 * NP + q, ib = (size_t)w * Kin * 5 * NP + q;
+    // kin_rows: rows of Hin in memory (= Kin, except for the first pair layer with a residual -- RES without DX --, whose input is the
+    // nf-row feature block: rows beyond it have no residual, and their cotangent is zero anyway: zero-padded weights downstream)
+    const size_t ob = (size_t)w * Kout * 5 * NP + q, ib = (size_t)w * kin_rows * 5 * NP + q;
     acc_t acc[NTI][5];
     for (int a = 0; a < NTI; ++a)
         for (int c = 0; c < 5; ++c) acc[a][c] = acc_t{0, 0, 0, 0};
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(256, 3) k_two_bwd(SysDev<T> S, const T* __rest
             const size_t o = ob + (size_t)(n * 5 + c) * NP;
             const T hb = HBn[o], ho = Hout[o];
             T y = ho;
-            if (RES) y = s2 * ho - Hin[ib + (size_t)(n * 5 + c) * NP];
+            if (RES) y = s2 * ho - ((DX || n < kin_rows) ? Hin[ib + (size_t)(n * 5 + c) * NP] : T(0));
             bv[c] = (RES ? hb * rs2 : hb) * (1 - y * y);
             Z2BAR[o] = bv[c];
         }

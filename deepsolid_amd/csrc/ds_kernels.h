@@ -270,6 +270,20 @@ __global__ void __launch_bounds__(256) k_layer_res_add(const T* __restrict__ Xin
     }
 }
 
+// The same for a first PAIR layer as wide as the pair features (network.py:527: hidden_double[0] == nf): the pair layer 0 runs without
+// its residual and this kernel finishes it in place, on the 5-jets (energy chain) or on five walker columns (value chain) alike:
+//   out[blk][n][c][pair] = ((n < n_res ? in[blk][n][c][pair] : 0) + out[blk][n][c][pair]) / sqrt 2,   n < Kout
+// grid (ceil(Kout * 5 * NP / 256), walkers | 5-walker blocks), block 256.
+template <typename T>
+__global__ void __launch_bounds__(256) k_pair_res_add(const T* __restrict__ Hin, int Kin, T* __restrict__ Hout, int Kout, int n_res, int NP) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Kout * 5 * NP) return;
+    const T* hi = Hin + (size_t)blockIdx.y * Kin * 5 * NP;
+    T* ho = Hout + (size_t)blockIdx.y * Kout * 5 * NP;
+    const T r = idx < (size_t)n_res * 5 * NP ? hi[idx] : T(0);
+    ho[idx] = (r + ho[idx]) * T(0.70710678118654752440);
+}
+
 // =====================================================================================
 // 2b. two-electron stream layer  h2 <- res(h2, tanh(h2 W + b))   (network.py:525-528)
 //     MFMA, C[n][(c,pair)] ; the five jet components of a pair sit in five accumulator tiles of the

@@ -44,8 +44,8 @@ def device_plan(hidden_dims, n_in_single, n_in_double=4, n_double=None):
     in == out of the REFERENCE's widths) -- an explicit flag per layer and stream, independent of the padded widths.
     `n_in_single` / `n_in_double`: widths of the input features (nf x atoms, nf); `n_double`: number of pair layers that run
     (network.py:118-121: the last width is unused without `use_last_layer`).  Raises ValueError for what the kernels cannot run:
-    widths beyond 1024 / 32, and a first PAIR layer as wide as the pair features (the reference's residual there).  A first
-    one-electron layer as wide as its input features runs (any width: the residual is added behind the layer)."""
+    widths beyond 1024 / 32.  A first layer as wide as its input features (either stream: the reference's residual there) runs for
+    any width: the residual is added behind the layer."""
     import ctypes as C
     lib = _lib.load()
     n = len(hidden_dims)

@@ -148,14 +148,14 @@ def test_shape_limits_are_rejected_at_create():
     for n_up, n_dn in ((30, 30), (41, 40), (54, 54), (64, 64)):
         assert 'null array' in err(n_up=n_up, n_dn=n_dn)
     # the descriptor carries the REFERENCE's widths: 200 or 24 are fine (zero-padded inside), refused are widths beyond the kernels'
-    # range and a first PAIR layer as wide as the pair features (the reference's residual there, network.py:527); a first
-    # one-electron layer as wide as its input features runs since round 6 (any width: the residual is added behind the layer)
+    # range; a first layer as wide as its input features (one-electron stream: nf x atoms, pair stream: nf -- the reference's
+    # residual there, network.py:525-528) runs since round 6 (any width: the residual is added behind the layer)
     assert 'null array' in err(hidden_single=[256, 200, 256], hidden_double=[32, 24, 32])
     assert 'hidden_single' in err(hidden_single=[2048, 256, 256])
     assert 'hidden_single' in err(hidden_single=[256, 0, 256])
     assert 'hidden_double' in err(hidden_double=[32, 40, 32])
     assert 'null array' in err(hidden_single=[4, 256, 256])          # n_atoms_prim = 1, 'nu': 4 input features: residual at layer 0, accepted
-    assert 'residual' in err(hidden_double=[4, 32, 32])
+    assert 'null array' in err(hidden_double=[4, 32, 32])
     # 16 atoms, 'nu': 64 input features = hidden_single[0] -> residual at layer 0 with K = 64 + 2 x 4 = 72 per-electron rows: accepted
     # (round 5 created the handle and failed at the first launch)
     assert 'null array' in err(n_atoms_prim=16, hidden_single=[64, 256, 256])

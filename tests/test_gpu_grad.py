@@ -195,11 +195,13 @@ def test_hidden_widths_without_kernel_instances(hidden_dims, use_last):
 
 
 @pytest.mark.parametrize('system,hidden_dims', [('lih', ((8, 16), (64, 16), (64, 16))),        # two atoms, 'nu': 8 input features = hidden_single[0]
-                                                ('bcc_li', ((4, 16), (4, 16), (64, 16)))])     # one atom: 4; layers 0 AND 1 residual at width 4
+                                                ('bcc_li', ((4, 16), (4, 16), (64, 16))),      # one atom: 4; layers 0 AND 1 residual at width 4
+                                                ('lih', ((64, 4), (64, 4), (64, 16))),         # pair stream: 4 pair features = hidden_double[0] (and [1])
+                                                ('lih', ((8, 4), (64, 16)))])                  # both streams at once, two layers
 def test_first_layer_as_wide_as_its_input_features(system, hidden_dims):
-    """hidden_single[0] == nf x atoms: the reference adds a residual at the FIRST layer (network.py:525-528).  Refused until round 6
+    """hidden_single[0] == nf x atoms (or hidden_double[0] == nf): the reference adds a residual at the FIRST layer (network.py:525-528).  Refused until round 6
     (its K = features + pair-mean rows is 64 k + 4 / + 8, and a width like 8 pads to 64 device features of which only 8 have a
-    residual); now layer 0 runs without its residual and csrc/ds_kernels.h::k_layer_res_add finishes it.  Loss, local energies and
+    residual); now layer 0 runs without its residual and csrc/ds_kernels.h::k_layer_res_add (k_pair_res_add) finishes it.  Loss, local energies and
     the energy gradient -- energy chain, value chain and reverse sweep -- against the oracle."""
     from deepsolid_amd import network as dnet, train as dtrain
     from oracle.testing import make_test_params
@@ -207,7 +209,7 @@ def test_first_layer_as_wide_as_its_input_features(system, hidden_dims):
     net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=hidden_dims)
     params = make_test_params(29, cell.original_cell.atom_coords(), cell.nelec, net_kw)
     net = dnet.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
-    assert net.apply.system.residuals[0][0] is True
+    assert any(net.apply.system.residuals[0])
     loss_fn = dtrain.make_loss(net.apply, None, cell, clip_local_energy=5.0, clip_type='real')
     dp = dev_params(params)
     xn = systems.synthetic_walkers(cell, 5, seed=23)

@@ -484,6 +484,33 @@ def test_padded_hidden_widths_on_the_benchmark_cell_vs_oracle():
         assert abs(complex(ke[b].cpu()) - complex(st['ke'])) < 1e-9 * max(1.0, abs(complex(st['ke'])))
 
 
+def test_first_pair_layer_residual_with_many_electrons_vs_oracle():
+    """hidden_double[0] == 4 on a cell with 8 + 8 electrons: the value chain of such cells normally takes the partner means from the
+    pair layer's own segment sums and runs all pair layers in one launch; with the reference's residual on the FIRST pair layer
+    (added behind the layer, k_pair_res_add) it must take the layer-by-layer path.  log|psi|, phase, E_kin against the oracle."""
+    from deepsolid_amd import hamiltonian, network, systems
+    from oracle.testing import make_test_params
+    cell, klist = systems.build('bcc_li', nelec=(8, 8))
+    net_kw = dict(systems.DETNET_DEFAULTS, hidden_dims=((64, 4), (64, 16), (64, 16)), determinants=2)
+    params = make_test_params(31, cell.original_cell.atom_coords(), cell.nelec, net_kw)
+    dp = dev_params(params)
+    p_cpu = onet.params_to_torch(params)
+    xn = systems.synthetic_walkers(cell, 2, seed=12)
+    x = torch.as_tensor(xn, device='cuda')
+    ps = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_phase_and_slogdet', **net_kw)
+    assert ps.apply.system.residuals[0] == (False, True)
+    phase, logabs = ps.apply(dp, x)
+    ld = network.make_solid_fermi_net(klist=klist, simulation_cell=cell, method_name='eval_logdet', **net_kw)
+    ke, _ = hamiltonian.local_energy_seperate(ld.apply, cell)(dp, x)
+    o_ps = oracle_net(cell, klist, net_kw, 'eval_phase_and_slogdet')
+    for b in range(2):
+        st = ofl.stages(p_cpu, tt(xn[b]), klist, cell, net_kw)
+        ph_ref, la_ref = o_ps.apply(p_cpu, tt(xn[b]))
+        assert abs(float(logabs[b]) - float(la_ref)) < 1e-10
+        assert abs(complex(phase[b].cpu()) - complex(ph_ref)) < 1e-10
+        assert abs(complex(ke[b].cpu()) - complex(st['ke'])) < 1e-9 * max(1.0, abs(complex(st['ke'])))
+
+
 @pytest.mark.parametrize('name', ['bcc_li_333', 'graphene_hex'])
 def test_blocked_determinant_traces_vs_scalar_kernel(name, monkeypatch):
     """Matrix sizes without a compile-time trace instance (odd sizes, float64 matrices whose slot tile of Y exceeds the LDS) run

@@ -375,8 +375,8 @@ def test_device_plan_follows_the_reference_residual_pattern():
     """deepsolid_amd/device.py::device_plan = the C ABI's ds_device_widths (host code, runs without a GPU): the widths the kernels
     run for the reference's hidden_dims (zero-padded weights, exact) and an EXPLICIT residual flag per layer and stream, set exactly
     where the reference adds a residual (network.py:525-528: in == out of the reference's widths) -- also at layer 0 of the
-    one-electron stream (round 6: any input width; the residual is added behind the layer, csrc/ds_kernels.h::k_layer_res_add);
-    a first PAIR layer as wide as the pair features is still refused."""
+    one-electron stream and of the pair stream (round 6: any input width; the residual is added behind the layer,
+    csrc/ds_kernels.h::k_layer_res_add / k_pair_res_add)."""
     import itertools
     from deepsolid_amd.device import device_plan, device_widths
     assert device_widths(((256, 32),) * 3, 4) == ((256, 32),) * 3
@@ -392,12 +392,14 @@ def test_device_plan_follows_the_reference_residual_pattern():
     assert device_plan(((64, 16), (64, 16)), 62)[1][0] == (False, False)        # 62 input rows pad to 64, but 62 != 64: none
     dev, res = device_plan(((8, 16), (8, 16)), 8)                      # layer 0 as wide as its 8 input features: residual at layer 0, device width 64
     assert dev == ((64, 16), (64, 16)) and res == ((True, False), (True, True))
+    dev, res = device_plan(((64, 4), (64, 4), (64, 4)), 4, 4)          # first pair layer as wide as the 4 pair features ('nu'): residual there too
+    assert dev == ((64, 16),) * 3 and res == ((False, True), (True, True), (True, True))
+    assert device_plan(((64, 7), (64, 7)), 7, 7, n_double=2)[1] == ((False, True), (True, True))      # 'tri': 7 pair features
     dev, res = device_plan(((256, 32), (256, 32), (256, 24)), 4, n_double=2)    # the last pair width is unused
     assert dev[:2] == ((256, 32),) * 2 and dev[2][0] == 256 and res[2] == (True, False)
     for bad, n_in, n_in2 in ((((64, 40), (64, 40)), 4, 4),              # pair widths beyond 32
                              (((2048, 16), (64, 16)), 4, 4),            # one-electron widths beyond 1024
-                             (((64, 4), (64, 4)), 4, 4),                # first pair layer as wide as the pair features ('nu': 4): the reference's residual there
-                             (((64, 7), (64, 7)), 7, 7)):               # ... ('tri': 7 features)
+                             (((64, 0), (64, 4)), 4, 4)):               # a pair width of zero
         with pytest.raises(ValueError):
             device_plan(bad, n_in, n_in2)
     singles, pairs = (40, 64, 100, 128, 130), (8, 16, 20, 32)
