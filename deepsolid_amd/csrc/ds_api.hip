@@ -101,6 +101,7 @@ struct ds_system {
     int val_nb = 0;                   // DS_VAL_NB = 1 / 2 / 4: one wave-tile width for the value chain's GEMMs (default: by workgroup count)
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
+    bool use_pm_skip = true;          // DS_NO_PM_SKIP unset: the dense float64 hidden layer skips the structurally zero slot tiles of its pair-mean rows
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
     int64_t val_i8_min_tiles = 512;   // (group, electron) tiles from which they do: two per CU (DS_I8_VAL_MIN_TILES overrides: measurements)
@@ -592,6 +593,9 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                                    (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
             } else if (res && !res_sep) {
                 ga.oe.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
+                // pair-mean rows of a hidden layer: structurally zero slot tiles are skipped (the kernel's 24-electron float64 instance;
+                // whole rounds of four k-steps per partner spin)
+                if (l > 0 && s->use_pm_skip && Kh % 16 == 0 && K2 % 16 == 0) { ga.oe.pm_k0 = Kh / 4; ga.oe.pm_ks = K2 / 4; ga.oe.pm_nup = S.n_up; ga.oe.pm_nch = S.nch; }
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }
                 layer_gemm(2, ga);
             } else {
@@ -1572,6 +1576,7 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
     if (const char* e = getenv("DS_VAL_NB")) { const int v = atoi(e); s->val_nb = (v == 1 || v == 2 || v == 4) ? v : 0; }
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
+    s->use_pm_skip = getenv("DS_NO_PM_SKIP") == nullptr;
     s->use_i8 = getenv("DS_I8") != nullptr && getenv("DS_NO_I8") == nullptr;
     s->use_ldsb = getenv("DS_NO_LDSB") == nullptr;
     s->use_pair_fuse = getenv("DS_NO_PAIR_FUSE") == nullptr;

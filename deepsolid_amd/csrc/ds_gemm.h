@@ -43,6 +43,10 @@ template <typename T> struct OrbEpi {
     // cycles (s_memtime) to clk[0] and its constant-rate 100 MHz ticks (s_memrealtime) to clk[1]
     unsigned long long* clk;
     int dbg;                        // DS_DBG & 32 (kernel development): one wave also writes phase stamps to clk[2 + i]
+    // dense hidden layer (EPI 2, the 24-electron float64 instance): the pair-mean rows -- k-steps pm_k0 .. of the contraction, pm_ks per
+    // partner spin -- are exactly zero outside slot tile 0, the electron's own tile(s) and the tiles of the partners' slots
+    // (k_m2_expand writes zeros there): the products on the other tiles are skipped.  pm_ks = 0: no such rows / no skipping
+    int pm_k0, pm_ks, pm_nup, pm_nch;
 };
 
 // Residual stash (EPI = 2 / 4): the residual rows of a layer are rows n0..n0+16*NB-1 of the SAME tile the wave streams as
@@ -433,6 +437,30 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 #pragma unroll
             for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
     };
+    // (pair-mean rows: a k-step under a wave-uniform slot-tile mask; bit-identical, the skipped products add exact zeros)
+    auto step_m = [&](int u, unsigned m) {
+#pragma unroll
+        for (int s = 0; s < ST; ++s)
+            if ((m >> s) & 1) {
+#pragma unroll
+                for (int a = 0; a < NB; ++a) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
+            }
+    };
+    constexpr bool PMASK = EPI == 2 && NB == 4 && ST == 5 && sizeof(T) == 8 && DS_SADD;
+    unsigned tmask[2] = {~0u, ~0u};
+    int pm_k0 = nks;                      // first masked k-step (nks: none)
+    if constexpr (PMASK) {
+        if (oe.pm_ks > 0 && tile < n_tiles) {
+            pm_k0 = oe.pm_k0;
+            const unsigned own = (1u << ((2 + 3 * tile) >> 4)) | (1u << ((4 + 3 * tile) >> 4));
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const int j0 = sp == 0 ? 0 : oe.pm_nup, ns = (sp == 0 || oe.pm_nch == 1) ? (oe.pm_nch == 1 ? n_tiles : oe.pm_nup) : n_tiles - oe.pm_nup;
+                const int lo = (2 + 3 * j0) >> 4, hi = (4 + 3 * (j0 + ns - 1)) >> 4;
+                tmask[sp] = 1u | own | (((2u << hi) - 1u) & ~((1u << lo) - 1u));
+            }
+        }
+    }
     // (compile-time choice: the launcher guarantees K % 16 == 0 for the ring instantiations -- gemm_uses_ring)
     if (gemm_uses_ring(EPI) || ((EPI == 6 || EPI == 7) && (nks & 3) == 0)) {      // (EPI 6 / 7: the long shared-term products too)
         // every load of the steady state is unconditional, so the outstanding-load count is the same on every path and the
@@ -442,9 +470,18 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         stamp();
         int ks = 0;
         if (NSET == 4) {
-            for (; ks + 4 < nks; ks += 4) {
+            for (; ks + 4 < ((PMASK && pm_k0 < nks) ? pm_k0 + 1 : nks); ks += 4) {      // (masked instance: up to k-step pm_k0 - 1)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { step(u, ks + u); load_set(u); }
+            }
+            if constexpr (PMASK) {
+                // the pair-mean rows (pm_k0 is a multiple of 4 k-steps and beyond the residual rows: nothing to park), but the last round
+                // (which runs unmasked below, with the shared term's loads in its shadow)
+                for (; ks + 4 < nks; ks += 4) {
+                    const unsigned m = tmask[(ks - pm_k0) >= oe.pm_ks ? 1 : 0];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { step_m(u, m); load_set(u); }
+                }
             }
             if constexpr (SADD) {
                 // the last four k-steps reload nothing: rows of S go into the registers of the sets as they die -- the full rows of

@@ -329,6 +329,37 @@ def test_lowrank_first_hidden_layer_vs_dense_path(name, monkeypatch):
 
 
 @pytest.mark.parametrize('no_lowrank', [False, True])
+def test_dense_layer_skips_the_zero_tiles_of_its_pair_mean_rows(no_lowrank, monkeypatch):
+    """Round 6: the pair-mean rows of a hidden layer's input (network.py:305-332) are exactly zero outside slot tile 0, the
+    electron's own tile(s) and the tiles of the partners' slots; k_jet_gemm<double,4,5,2> skips the products on the other tiles
+    (wave-uniform masks per round of four k-steps).  The skipped products add exact zeros: with DS_NO_PM_SKIP=1 (every product
+    executed) the energies must be IDENTICAL to the last bit, and both reproduce the reference-executed kinetic energies; with
+    DS_NO_LOWRANK=1 layers 1 and 2 run the dense kernel."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case('bcc_li')
+    dp = dev_params(params)
+    nw = min(4, len(fx['ke_ref']))
+    x = torch.as_tensor(fx['x'][:nw], device='cuda')
+    monkeypatch.delenv('DS_I8', raising=False)
+    if no_lowrank:
+        monkeypatch.setenv('DS_NO_LOWRANK', '1')
+    else:
+        monkeypatch.delenv('DS_NO_LOWRANK', raising=False)
+    out = {}
+    for flag in (None, '1'):
+        if flag:
+            monkeypatch.setenv('DS_NO_PM_SKIP', flag)
+        else:
+            monkeypatch.delenv('DS_NO_PM_SKIP', raising=False)
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
+        out[flag] = torch.view_as_complex(sysd.local_energy(dp, x)[0]).cpu().numpy()
+        for b in range(nw):
+            assert abs(out[flag][b] - fx['ke_ref'][b]) < 1e-9 * max(1.0, abs(fx['ke_ref'][b])), (flag, b, out[flag][b], fx['ke_ref'][b])
+    assert np.array_equal(out[None], out['1'])
+
+
+@pytest.mark.parametrize('no_lowrank', [False, True])
 def test_int8_split_hidden_layer_vs_float64_kernel(no_lowrank, monkeypatch):
     """The dense residual hidden layers of the 5-slot-tile float64 cells (bcc-Li 2x2x2: layer 2; with DS_NO_LOWRANK=1 layers 1 and 2)
     can run their per-electron contraction as a truncating fixed-point split on the int8 matrix pipe (csrc/ds_i8.h: 47-bit fixed point under one
