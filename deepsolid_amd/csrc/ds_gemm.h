@@ -783,22 +783,32 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
         // slots and the tiles of the partners' slots (k_m2_expand writes exact zeros elsewhere): with 12 + 12 electrons a spin-up row
         // fills tiles 0 .. 2 (+ the own tile of a spin-down electron), a spin-down row tiles 0, 2 .. 4: the products on the other
         // tiles add exact zeros and are skipped (wave-uniform mask per k-step; bit-identical).
-        unsigned tmask[2];
+        // The low-rank rows (round 6) have the same structure and NO value / Laplacian entries (zeroed below): the electron's own
+        // features (the first h1[0] rows of the layer-0 input) live in its own tile(s) only, the layer-0 pair-mean rows and the spin-mean
+        // rows of partner spin sp in the own tile(s) and the partners' tiles -- lmask, without slot tile 0.
+        unsigned tmask[2], lmask[2];
+        const unsigned own = (1u << ((2 + 3 * tile) >> 4)) | (1u << ((4 + 3 * tile) >> 4));
         {
             const int n_dn = A.n_tiles - A.n_up;
-            const unsigned own = (1u << ((2 + 3 * tile) >> 4)) | (1u << ((4 + 3 * tile) >> 4));
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const int j0 = sp == 0 ? 0 : A.n_up, ns = (sp == 0 || A.nch == 1) ? (A.nch == 1 ? A.n_tiles : A.n_up) : n_dn;
                 const int lo = (2 + 3 * j0) >> 4, hi = (4 + 3 * (j0 + ns - 1)) >> 4;
-                tmask[sp] = 1u | own | (((2u << hi) - 1u) & ~((1u << lo) - 1u));
+                lmask[sp] = own | (((2u << hi) - 1u) & ~((1u << lo) - 1u));
+                tmask[sp] = 1u | lmask[sp];
             }
         }
         const int nm2s = A.nch > 1 ? nm2 / 2 : nm2;            // k-steps of the first partner spin's rows
+        const int h10 = A.K0sh / A.nch / 4, h20 = (nl - h10) / A.nch;      // k-steps of the own-feature rows / of one spin's layer-0 pair-mean rows
+        auto low_mask = [&](int kk) -> unsigned {               // kk: k-step among the low-rank rows (K0loc rows of XL, then K0sh rows of M0)
+            if (kk < h10) return own;
+            if (kk < nl) return lmask[(kk - h10) >= h20 ? 1 : 0];
+            return lmask[(kk - nl) >= h10 ? 1 : 0];
+        };
         auto step = [&](int u, int k) {
             const bool low = k >= nm2;
             const int c = low ? 4 * (k - nm2) : 0;
-            const unsigned m = low ? ~0u : tmask[k < nm2s ? 0 : 1];
+            const unsigned m = low ? low_mask(k - nm2) : tmask[k < nm2s ? 0 : 1];
             T b0 = bv[u][0];
             b0 = (low && lr < 2) ? T(0) : b0;
             T aa[NB];
@@ -851,6 +861,18 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
         // G1[n][s] = y'_n z0[n][s] for s >= 2, (y_n, oL_n) in slots 0 / 1
         const T* Xl = A.XL + (size_t)w * A.xl_ws + (size_t)tile * A.xl_ts + (size_t)lq * P + lr;
         const T* S0p = A.S0 + (size_t)w * Kh * P + lr;
+        unsigned rm_sp[2];
+        const unsigned rm_own = (1u << ((2 + 3 * tile) >> 4)) | (1u << ((4 + 3 * tile) >> 4));
+        {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const int j0 = sp == 0 ? 0 : A.n_up, ns = (sp == 0 || A.nch == 1) ? (A.nch == 1 ? A.n_tiles : A.n_up) : A.n_tiles - A.n_up;
+                const int lo = (2 + 3 * j0) >> 4, hi = (4 + 3 * (j0 + ns - 1)) >> 4;
+                rm_sp[sp] = rm_own | (((2u << hi) - 1u) & ~((1u << lo) - 1u));
+            }
+        }
+        const int rh10 = A.K0sh / A.nch / 4, rh20 = (A.K0loc / 4 - rh10) / A.nch;
+        auto rmask = [&](int ks) -> unsigned { return ks < rh10 ? rm_own : rm_sp[(ks - rh10) >= rh20 ? 1 : 0]; };
         auto rf = [&](int a) {
             const T rs2 = T(0.70710678118654752440);
             // (at most five slot tiles at a time: the recomputed rows then take 40 registers next to the accumulators)
@@ -868,9 +890,11 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
                 }
                 for (int ks = 0; ks < A.K0loc / 4; ++ks) {
                     const T av = A.W0[(size_t)(4 * ks + lq) * Kh + n0 + 16 * a + lr];
+                    // (the same structural zeros as in phase 2; slots 0 / 1 of the recomputed rows are replaced by (y, oL) below)
+                    const unsigned mr = rmask(ks) >> c0;
 #pragma unroll
                     for (int s = 0; s < CWMAX; ++s)
-                        if (s < cw) racc[s] = mfma16(av, Xl[(size_t)(4 * ks) * P + 16 * (c0 + s)], racc[s]);
+                        if (s < cw && ((mr >> s) & 1)) racc[s] = mfma16(av, Xl[(size_t)(4 * ks) * P + 16 * (c0 + s)], racc[s]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
