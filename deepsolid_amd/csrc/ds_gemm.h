@@ -1018,6 +1018,14 @@ k_layer0_stats(SysDev<T> S, const T* __restrict__ XL, size_t xl_ws, size_t xl_ts
             for (int t = 0; t < ST; ++t) xn[ks][t] = Xl[(size_t)(4 * ks) * P + 16 * t];
     };
     load_x(i0);
+    const int h10 = S.h1[0] / 4, h20 = S.h2[0] / 4;      // k-steps of the own-feature rows / of one partner spin's pair-mean rows
+    unsigned prange[2];
+#pragma unroll
+    for (int sp2 = 0; sp2 < 2; ++sp2) {
+        const int j0 = sp2 == 0 ? 0 : S.n_up, nsp = sp2 == 0 ? S.n_up : (S.n_dn > 0 ? S.n_dn : S.n_up);
+        const int lo = (2 + 3 * j0) >> 4, hi = (4 + 3 * (j0 + nsp - 1)) >> 4;
+        prange[sp2] = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+    }
     for (int e = 0; e < ns; ++e) {
         const int i = i0 + e;
         acc_t acc[ST];
@@ -1029,10 +1037,16 @@ k_layer0_stats(SysDev<T> S, const T* __restrict__ XL, size_t xl_ws, size_t xl_ts
 #pragma unroll
             for (int t = 0; t < ST; ++t) xc[ks][t] = xn[ks][t];
         load_x(i0 + (e + 1 < ns ? e + 1 : e));          // (unconditional: the last electron is requested twice)
+        // structural zeros of the layer-0 input rows (round 6; as in k_layer1_lr): the electron's own features fill slot tile 0 (value,
+        // Laplacian) and its own tile(s), the pair-mean rows of partner spin sp also the partners' tiles; the other products add exact zeros
+        const unsigned own = 1u | (1u << ((2 + 3 * i) >> 4)) | (1u << ((4 + 3 * i) >> 4));
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
+        for (int ks = 0; ks < NKS; ++ks) {
+            const unsigned m = ks < h10 ? own : (own | prange[(ks - h10) >= h20 ? 1 : 0]);
 #pragma unroll
-            for (int t = 0; t < ST; ++t) acc[t] = mfma16(wv[ks], xc[ks][t], acc[t]);
+            for (int t = 0; t < ST; ++t)
+                if ((m >> t) & 1) acc[t] = mfma16(wv[ks], xc[ks][t], acc[t]);
+        }
         T* yo = YO + ((size_t)w * S.N + i) * 2 * Nout;
         // tanh of the four value slots in one evaluation (lane lr < 4 of every row takes row group lr)
         T zsel = 0;
