@@ -493,8 +493,16 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
         {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
             const bool xl = lr_on && l == 0;
+            // the structurally zero slot tiles of the rows are left unwritten when this layer's kernel never uses them: the low-rank
+            // layer 1 (every pair-mean k-step under the tile masks) and the 24-electron float64 dense layer (all but its last round)
+            int skip = 0;
+            if (!dr && s->use_pm_skip && sizeof(T) == 8 && NB == 4 && ST == 5 && !wide && l >= 1) {
+                const int Kloc_l = Kh + S.nch * K2;
+                if (lr_on && l == 1) skip = 1;
+                else if (s->res1[l] && Kloc_l % 16 == 0 && Kh % 16 == 0 && K2 % 16 == 0 && !int8_layer(s, l) && DS_SADD) skip = 2;
+            }
             hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
-                               c.H2[hi], K2, xl ? c.XL : c.G[gi], Kh, xl ? K0loc : S.ldk);
+                               c.H2[hi], K2, xl ? c.XL : c.G[gi], Kh, xl ? K0loc : S.ldk, skip);
         }
         if (stop == STOP_G0 + l) return copy_out(dr, c.G[gi], L.G * Bc, st);
         // pair stream layer
@@ -617,7 +625,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     if (s->use_last) {
         ProfScope ps(s, DS_PROF_M2_EXPAND, st);
         hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2l, S.N)), dim3(256), (size_t)(K2l * 5 * S.N + S.nch * K2l * 5) / m2_split<T>(K2l, S.N) * sizeof(T), st, S,
-                           c.H2[hi], K2l, c.G[gi], Kl, S.ldk);
+                           c.H2[hi], K2l, c.G[gi], Kl, S.ldk, 0);
     }
     for (int sp = 0; sp < S.nch; ++sp) {
         const int ns = sp == 0 ? S.n_up : S.n_dn, i0 = sp == 0 ? 0 : S.n_up, OC = S.ocols[sp];
