@@ -496,10 +496,13 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             // the structurally zero slot tiles of the rows are left unwritten when this layer's kernel never uses them: the low-rank
             // layer 1 (every pair-mean k-step under the tile masks) and the 24-electron float64 dense layer (all but its last round)
             int skip = 0;
-            if (!dr && s->use_pm_skip && sizeof(T) == 8 && NB == 4 && ST == 5 && !wide && l >= 1) {
+            if (!dr && s->use_pm_skip && l >= 1) {
                 const int Kloc_l = Kh + S.nch * K2;
-                if (lr_on && l == 1) skip = 1;
-                else if (s->res1[l] && Kloc_l % 16 == 0 && Kh % 16 == 0 && K2 % 16 == 0 && !int8_layer(s, l) && DS_SADD) skip = 2;
+                // (the chunked kernels of ds_wide.h have no masks: what they take over keeps every slot)
+                const bool wide_lr = wide && (s->wide_all || (sizeof(T) == 8 && lr_nc <= 2)), wide_gemm = wide && (s->wide_all || sizeof(T) == 8);
+                if (lr_on && l == 1) skip = wide_lr ? 0 : 1;
+                else if (s->res1[l] && Kloc_l % 16 == 0 && Kh % 16 == 0 && K2 % 16 == 0 && !int8_layer(s, l) && !wide_gemm && ds::pm_instance<T>(ST))
+                    skip = (sizeof(T) == 8 && NB == 4 && ST == 5 && DS_SADD) ? 2 : 1;
             }
             hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
                                c.H2[hi], K2, xl ? c.XL : c.G[gi], Kh, xl ? K0loc : S.ldk, skip);
@@ -601,8 +604,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                                    (const double*)sw, (const double*)Sl, S.N, (double*)c.G[gi ^ 1], ntiles);
             } else if (res && !res_sep) {
                 ga.oe.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
-                // pair-mean rows of a hidden layer: structurally zero slot tiles are skipped (the kernel's 24-electron float64 instance;
-                // whole rounds of four k-steps per partner spin)
+                // pair-mean rows of a hidden layer: structurally zero slot tiles are skipped (whole rounds of four k-steps per partner spin)
                 if (l > 0 && s->use_pm_skip && Kh % 16 == 0 && K2 % 16 == 0) { ga.oe.pm_k0 = Kh / 4; ga.oe.pm_ks = K2 / 4; ga.oe.pm_nup = S.n_up; ga.oe.pm_nch = S.nch; }
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }
                 layer_gemm(2, ga);

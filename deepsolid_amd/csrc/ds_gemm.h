@@ -64,6 +64,13 @@ template <typename T, int NB, int ST> inline size_t gemm_stash_bytes(unsigned th
     return (size_t)(threads / 64) * stash_blocks<T, NB, ST>() * 4 * ST * 64 * sizeof(T);
 }
 
+// Residual-layer instances (k_jet_gemm<T, NB, ST, 2>) that skip the structurally zero slot tiles of the pair-mean rows: float64 up to
+// 20 slot tiles (beyond, the masked rounds spill -- cells that run the chunked kernels of ds_wide.h anyway).  ds_api.hip asks the same
+// question before it lets k_m2_expand leave those tiles unwritten.
+// float64 only: a float32 MFMA lasts 32 cycles, a mask branch then guards too little work (diamond f32, 19 tiles: hidden layers
+// 45.2 -> 48.1 ms WITH the masks); a float64 branch guards 128-256 cycles of products.
+template <typename T> constexpr bool pm_instance(int st) { return sizeof(T) == 8 && st <= 20; }
+
 // Depth of the operand ring: as many k-steps of operands as the register file leaves next to the accumulators (256 VGPRs per
 // wave with two waves per SIMD, 512 for the four-wave workgroups of the widest tiles), at most four, at least two.
 template <typename T, int NB, int ST> constexpr int ring_sets() {
@@ -446,7 +453,18 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                 for (int a = 0; a < NB; ++a) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
             }
     };
-    constexpr bool PMASK = EPI == 2 && NB == 4 && ST == 5 && sizeof(T) == 8 && DS_SADD;
+    auto park = [&](int u, int k) {      // (the residual parking of `step`, for the masked rounds that straddle pm_k0)
+        if (NA > 0) {
+            const int j = k - (n0 >> 2);
+            if (j >= 0 && j < 4 * NA) {
+#pragma unroll
+                for (int s = 0; s < ST; ++s) stash[(j * ST + s) * 64 + lane] = bv[u][s];
+            }
+        }
+    };
+    // every residual-layer instance masks; the 24-electron float64 one (shared term added in the epilogue, SADD below) leaves its last
+    // round of four k-steps unmasked, the others mask every pair-mean k-step
+    constexpr bool PMASK = EPI == 2 && pm_instance<T>(ST);
     unsigned tmask[2] = {~0u, ~0u};
     int pm_k0 = nks;                      // first masked k-step (nks: none)
     if constexpr (PMASK) {
@@ -461,6 +479,11 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
             }
         }
     }
+    auto pm_mask = [&](int k) -> unsigned { return tmask[(k - pm_k0) >= oe.pm_ks ? 1 : 0]; };
+    auto step_g = [&](int u, int k) {      // a k-step on either side of pm_k0: ONE code path (two inlined variants per call spill)
+        if constexpr (PMASK) { park(u, k); step_m(u, k >= pm_k0 ? pm_mask(k) : ~0u); }
+        else step(u, k);
+    };
     // (compile-time choice: the launcher guarantees K % 16 == 0 for the ring instantiations -- gemm_uses_ring)
     if (gemm_uses_ring(EPI) || ((EPI == 6 || EPI == 7) && (nks & 3) == 0)) {      // (EPI 6 / 7: the long shared-term products too)
         // every load of the steady state is unconditional, so the outstanding-load count is the same on every path and the
@@ -502,6 +525,10 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                     for (int q = 0; q < NB * 4; ++q)
                         if ((q & 3) == u) { if (q < NSF) lfull(q); else s0[q] = srow(q)[0]; }
                 }
+            } else if constexpr (PMASK) {
+                const unsigned m = pm_k0 < nks ? pm_mask(ks) : ~0u;      // (pm_ks is a multiple of four k-steps: one partner spin per round)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { park(u, ks + u); step_m(u, m); }
             } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) step(u, ks + u);
@@ -509,19 +536,25 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         } else {
             // fewer sets (wide slot ranges: the accumulators leave room for two or three): nks need not divide, the last
             // one or two rounds reload conditionally
-            for (; ks + 2 * NSET <= nks; ks += NSET) {
+            for (; ks + 2 * NSET <= nks && (!PMASK || ks + NSET <= pm_k0); ks += NSET) {      // (rounds in front of the pair-mean rows)
 #pragma unroll
                 for (int u = 0; u < NSET; ++u) { step(u, ks + u); load_set(u); }
             }
+            if constexpr (PMASK) {
+                for (; ks + 2 * NSET <= nks; ks += NSET) {
+#pragma unroll
+                    for (int u = 0; u < NSET; ++u) { step_g(u, ks + u); load_set(u); }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < NSET; ++u) {
-                step(u, ks + u);
+                step_g(u, ks + u);
                 if (ks + u + NSET < nks) load_set(u);
             }
             ks += NSET;
 #pragma unroll
             for (int u = 0; u < NSET; ++u)
-                if (ks + u < nks) step(u, ks + u);
+                if (ks + u < nks) step_g(u, ks + u);
         }
     } else {
         // short contractions (layer 0: K = 12, 8): one set, no ring
@@ -808,7 +841,8 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
         auto step = [&](int u, int k) {
             const bool low = k >= nm2;
             const int c = low ? 4 * (k - nm2) : 0;
-            const unsigned m = low ? low_mask(k - nm2) : tmask[k < nm2s ? 0 : 1];
+            // (float32: the low-rank rows stay unmasked -- diamond f32 measured 32.9 -> 35.4 ms with them masked)
+            const unsigned m = low ? (sizeof(T) == 8 ? low_mask(k - nm2) : ~0u) : tmask[k < nm2s ? 0 : 1];
             T b0 = bv[u][0];
             b0 = (low && lr < 2) ? T(0) : b0;
             T aa[NB];
@@ -872,7 +906,7 @@ __global__ void __launch_bounds__((ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1)
             }
         }
         const int rh10 = A.K0sh / A.nch / 4, rh20 = (A.K0loc / 4 - rh10) / A.nch;
-        auto rmask = [&](int ks) -> unsigned { return ks < rh10 ? rm_own : rm_sp[(ks - rh10) >= rh20 ? 1 : 0]; };
+        auto rmask = [&](int ks) -> unsigned { return sizeof(T) == 4 ? ~0u : (ks < rh10 ? rm_own : rm_sp[(ks - rh10) >= rh20 ? 1 : 0]); };
         auto rf = [&](int a) {
             const T rs2 = T(0.70710678118654752440);
             // (at most five slot tiles at a time: the recomputed rows then take 40 registers next to the accumulators)
