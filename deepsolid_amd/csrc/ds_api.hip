@@ -494,7 +494,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
             const bool xl = lr_on && l == 0;
             // the structurally zero slot tiles of the rows are left unwritten when this layer's kernel never uses them: the low-rank
-            // layer 1 (every pair-mean k-step under the tile masks) and the 24-electron float64 dense layer (all but its last round)
+            // layer 1 and the float64 dense layers (every pair-mean k-step under the tile masks)
             int skip = 0;
             if (!dr && s->use_pm_skip && l >= 1) {
                 const int Kloc_l = Kh + S.nch * K2;
@@ -502,7 +502,7 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 const bool wide_lr = wide && (s->wide_all || (sizeof(T) == 8 && lr_nc <= 2)), wide_gemm = wide && (s->wide_all || sizeof(T) == 8);
                 if (lr_on && l == 1) skip = wide_lr ? 0 : 1;
                 else if (s->res1[l] && Kloc_l % 16 == 0 && Kh % 16 == 0 && K2 % 16 == 0 && !int8_layer(s, l) && !wide_gemm && ds::pm_instance<T>(ST))
-                    skip = (sizeof(T) == 8 && NB == 4 && ST == 5 && DS_SADD) ? 2 : 1;
+                    skip = 1;
             }
             hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
                                c.H2[hi], K2, xl ? c.XL : c.G[gi], Kh, xl ? K0loc : S.ldk, skip);

@@ -462,8 +462,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
             }
         }
     };
-    // every residual-layer instance masks; the 24-electron float64 one (shared term added in the epilogue, SADD below) leaves its last
-    // round of four k-steps unmasked, the others mask every pair-mean k-step
+    // every float64 residual-layer instance masks every pair-mean k-step
     constexpr bool PMASK = EPI == 2 && pm_instance<T>(ST);
     unsigned tmask[2] = {~0u, ~0u};
     int pm_k0 = nks;                      // first masked k-step (nks: none)
@@ -499,7 +498,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
             }
             if constexpr (PMASK) {
                 // the pair-mean rows (pm_k0 is a multiple of 4 k-steps and beyond the residual rows: nothing to park), but the last round
-                // (which runs unmasked below, with the shared term's loads in its shadow)
+                // (below, with the shared term's loads in its shadow)
                 for (; ks + 4 < nks; ks += 4) {
                     const unsigned m = tmask[(ks - pm_k0) >= oe.pm_ks ? 1 : 0];
 #pragma unroll
@@ -518,9 +517,10 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
                     for (int s = 0; s < ST; ++s) sfull[q][s] = p[16 * s];
                     s0[q] = sfull[q][0];
                 };
+                const unsigned mlast = (PMASK && pm_k0 < nks) ? pm_mask(ks) : ~0u;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    step(u, ks + u);
+                    if constexpr (PMASK) step_m(u, mlast); else step(u, ks + u);      // (the last round carries no residual rows: nothing to park)
 #pragma unroll
                     for (int q = 0; q < NB * 4; ++q)
                         if ((q & 3) == u) { if (q < NSF) lfull(q); else s0[q] = srow(q)[0]; }

@@ -207,8 +207,8 @@ __global__ void __launch_bounds__(256) k_features(SysDev<T> S, const T* __restri
 // grid.z splits the K2 pair features (the pair jets of a split then fit several workgroups' worth of LDS per CU)
 // skip (round 6): the rows are exactly zero outside slot tile 0, the electron's own tile(s) and the tiles of the partner spin's slots.
 //   0: every slot of every row is written;  1: the structurally zero tiles are NOT written -- only for consumers that never use them
-//   (k_layer1_lr: all pair-mean k-steps run under the tile masks);  2: the same, but the last 16 rows in full (k_jet_gemm<double,4,5,2>
-//   runs its last round of four k-steps unmasked).  What is left unwritten holds stale numbers of an earlier layer: loaded, never used.
+//   (k_layer1_lr and the float64 k_jet_gemm<.., 2> instances: all pair-mean k-steps run under the tile masks).  What is left
+//   unwritten holds stale numbers of an earlier layer: loaded by the operand ring, never multiplied.
 template <typename T>
 __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restrict__ H2, int K2, T* __restrict__ G, int row0, int ldg, int skip) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) k_m2_expand(SysDev<T> S, const T* __restr
     for (int idx = tid; idx < S.nch * Kc * QP; idx += nt) {
         const int row = idx / QP, sq = idx - row * QP, k = row % Kc, s = row / Kc;
         const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
-        if (skip && !(skip == 2 && s == S.nch - 1 && k0 + k >= K2 - 16)) {
+        if (skip) {
             const int t = sq >> 2, lo = (2 + 3 * j0) >> 4, hi = (4 + 3 * (j0 + ns - 1)) >> 4;
             if (!(t == 0 || t == ((2 + 3 * e) >> 4) || t == ((4 + 3 * e) >> 4) || (t >= lo && t <= hi))) continue;
         }
