@@ -656,6 +656,22 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
     T* Tw = TR + (size_t)w * tr_stride + tr_off + (size_t)kdet * 2 * P;
     // A fragments (slot independent): A[n' = (e, ri')][k' = (m, ri)]
     T af[NT][KSMAX];
+    if constexpr (NFIX > 0) {
+        // compile-time size: every fragment element is ONE unconditional 2-element load (clamped index, selected afterwards) -- all in
+        // flight together instead of a branch and a wait per element (setup: 10 k of the 70 k cycles a workgroup lives, round 6)
+        typedef T vec2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks) {
+                if (4 * ks >= n2) { af[nt][ks] = 0; continue; }
+                const int np = 16 * nt + lr, kp = 4 * ks + lq, npc = np < n2 ? np : n2 - 1;
+                const int e = npc >> 1, rip = npc & 1, m = kp >> 1, ri = kp & 1;
+                const vec2 c = *reinterpret_cast<const vec2*>(Iw + (m * n + e) * 2);
+                const T v = (ri == rip) ? c[0] : (rip == 0 ? -c[1] : c[1]);
+                af[nt][ks] = np < n2 ? v : T(0);
+            }
+    } else {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -669,6 +685,7 @@ __global__ void __launch_bounds__(64 * NW) k_det_trace_mfma(SysDev<T> S, const T
             }
             af[nt][ks] = v;
         }
+    }
     Cx<T> y2(0, 0);
     const int d = tid % SW, g = tid / SW;
     // The wave's rows over ALL slot tiles form one sequence q = (pass, row): the B operands of row q + 2 are requested before
