@@ -572,6 +572,8 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             };
             ds::GemmArgs<T> ga{Xin, xws, xts, blk(s->i_wloc[l]), Kloc, nullptr, 0, nullptr, 0, S.N, c.G[gi ^ 1], gws, gts, Nout, S.P, c.ZB, blk(s->i_b[l]),
                                ds::OrbEpi<T>{}};
+            // layer 0 (EPI 1 / 9): own-feature rows, then the pair-mean rows per partner spin -- structurally zero slot tiles are skipped
+            if (l == 0 && s->use_pm_skip) { ga.oe.pm_k0 = S.h1[0] / 4; ga.oe.pm_ks = S.h2[0] / 4; ga.oe.pm_nup = S.n_up; ga.oe.pm_nch = S.nch; }
             if (lr_on && l == 1) {
                 // first hidden layer on the low-rank form of the layer-0 output (ds_gemm.h: k_layer1_lr)
                 const ds::LrArgs<T> la{c.XL, (size_t)S.N * K0loc * S.P, (size_t)K0loc * S.P, c.MEAN[0], (size_t)K0sh * S.P, K0loc, K0sh,

@@ -464,12 +464,16 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     };
     // every float64 residual-layer instance masks every pair-mean k-step
     constexpr bool PMASK = EPI == 2 && pm_instance<T>(ST);
+    // ... and layer 0 (EPI 1 / 9, the plain loop below): its own-feature rows (k-steps below pm_k0) fill slot tile 0 and the own tile(s)
+    constexpr bool PM0 = (EPI == 1 || EPI == 9) && pm_instance<T>(ST);
     unsigned tmask[2] = {~0u, ~0u};
     int pm_k0 = nks;                      // first masked k-step (nks: none)
-    if constexpr (PMASK) {
+    unsigned own0 = ~0u;                  // (layer 0) mask of the own-feature rows
+    if constexpr (PMASK || PM0) {
         if (oe.pm_ks > 0 && tile < n_tiles) {
             pm_k0 = oe.pm_k0;
             const unsigned own = (1u << ((2 + 3 * tile) >> 4)) | (1u << ((4 + 3 * tile) >> 4));
+            own0 = 1u | own;
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 const int j0 = sp == 0 ? 0 : oe.pm_nup, ns = (sp == 0 || oe.pm_nch == 1) ? (oe.pm_nch == 1 ? n_tiles : oe.pm_nup) : n_tiles - oe.pm_nup;
@@ -558,7 +562,11 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         }
     } else {
         // short contractions (layer 0: K = 12, 8): one set, no ring
-        for (int ks = 0; ks < nks; ++ks) { load_set(0); step(0, ks); }
+        if constexpr (PM0) {
+            for (int ks = 0; ks < nks; ++ks) { load_set(0); step_m(0, pm_k0 < nks ? (ks < pm_k0 ? own0 : pm_mask(ks)) : ~0u); }
+        } else {
+            for (int ks = 0; ks < nks; ++ks) { load_set(0); step(0, ks); }
+        }
     }
     stamp();
     if (EPI == 0 || EPI == 6 || EPI == 7) {
@@ -978,6 +986,14 @@ k_layer0_means(SysDev<T> S, const T* __restrict__ XL, size_t xl_ws, size_t xl_ts
         for (int r = 0; r < 4; ++r) s0[s][r] = S0[(size_t)w * Nout * P + (size_t)(n0 + acc_row<T>(lane, r)) * P + 16 * t + lr];
         macc[s] = acc_t{0, 0, 0, 0};
     }
+    const int h10 = S.h1[0] / 4, h20 = S.h2[0] / 4;
+    unsigned prange[2];
+#pragma unroll
+    for (int sp2 = 0; sp2 < 2; ++sp2) {
+        const int j0 = sp2 == 0 ? 0 : S.n_up, nsp = sp2 == 0 ? S.n_up : (S.n_dn > 0 ? S.n_dn : S.n_up);
+        const int lo = (2 + 3 * j0) >> 4, hi = (4 + 3 * (j0 + nsp - 1)) >> 4;
+        prange[sp2] = ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+    }
     for (int e = 0; e < ns; ++e) {
         const int i = i0 + e;
         const T* Xl = XL + (size_t)w * xl_ws + (size_t)i * xl_ts + (size_t)lq * P + lr;
@@ -988,13 +1004,17 @@ k_layer0_means(SysDev<T> S, const T* __restrict__ XL, size_t xl_ws, size_t xl_ts
         acc_t acc[STC];
 #pragma unroll
         for (int s = 0; s < STC; ++s) acc[s] = s0[s];
+        // (float64: the structurally zero slot tiles of the input rows are skipped, as in k_layer0_stats)
+        const unsigned own = 1u | (1u << ((2 + 3 * i) >> 4)) | (1u << ((4 + 3 * i) >> 4));
         for (int ks = 0; ks < nks; ++ks) {
             const T wv = W0p[(size_t)(4 * ks) * Nout];
             T xv[STC];
 #pragma unroll
             for (int s = 0; s < STC; ++s) xv[s] = Xl[(size_t)(4 * ks) * P + 16 * (t0 + s < ntile ? t0 + s : ntile - 1)];
+            const unsigned m = sizeof(T) == 8 ? ((ks < h10 ? own : (own | prange[(ks - h10) >= h20 ? 1 : 0])) >> t0) : ~0u;
 #pragma unroll
-            for (int s = 0; s < STC; ++s) acc[s] = mfma16(wv, xv[s], acc[s]);
+            for (int s = 0; s < STC; ++s)
+                if ((m >> s) & 1) acc[s] = mfma16(wv, xv[s], acc[s]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
