@@ -7,10 +7,12 @@ set -x
 mkdir -p gpurun_out/final_$TAG
 F=gpurun_out/final_$TAG
 python -m pytest tests -m gpu -q -k "int8" 2>&1 | tail -2 > $F/int8_tests.txt
+# the traffic pass first, and its summary into profiles/ ON THIS BOX: the bench line's `roofline.traffic` then comes from the same box
+bash tools/pmc_traffic.sh $TAG > $F/pmc_traffic.txt 2>&1
+cp gpurun_out/pmc_$TAG/summary.json profiles/${TAG}_pmc_traffic.json
 python bench.py > $F/bench.json 2> $F/bench.err
 tail -c 900 $F/bench.json
 bash tools/profile_bench.sh ${TAG}_bench > $F/prof.txt 2>&1
-bash tools/pmc_traffic.sh $TAG > $F/pmc_traffic.txt 2>&1
 bash tools/pmc_mfma.sh $TAG > $F/pmc_mfma.json 2> $F/pmc_mfma.err
 bash tools/profile_cmd.sh ${TAG}_value tools/value_driver.py > /dev/null 2>&1
 bash tools/profile_cmd.sh ${TAG}_vjp tools/grad_bench.py bcc_li 4096 vjp > /dev/null 2>&1
