@@ -101,6 +101,7 @@ struct ds_system {
     int val_nb = 0;                   // DS_VAL_NB = 1 / 2 / 4: one wave-tile width for the value chain's GEMMs (default: by workgroup count)
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
+    bool use_pair_expand = true;      // DS_NO_PAIR_EXPAND unset: a pair layer writes the pair-mean rows of the next one-electron layer itself (k_two_layer_expand)
     bool use_pm_skip = true;          // DS_NO_PM_SKIP unset: the dense float64 hidden layer skips the structurally zero slot tiles of its pair-mean rows
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
     void* lr_w0t = nullptr;           // transposed / padded layer-0 weights of that kernel, refilled from the parameters at every call
@@ -486,27 +487,28 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
     if (stop == STOP_H2_0) return copy_out(dr, c.H2[0], (size_t)S.h2[0] * 5 * S.NP * Bc, st);
     if (stop == STOP_Q) return copy_out(dr, c.Q, L.Q * Bc, st);
     int gi = 0, hi = 0, mi = 0;       // current G / H2 / MEAN buffer
+    bool expanded = false;            // the pair-mean rows of the coming layer were written by the pair layer behind them (k_two_layer_expand)
     for (int l = 0; l < S.n_layers; ++l) {
         const int Kh = S.h1[l], K2 = S.h2[l], Nout = S.h1[l + 1];
         if (Nout % 64 || Nout > 1024) return fail("hidden_single must be a multiple of 64 and <= 1024 (got %d)", Nout);
         // spin means of the pair stream -> rows [Kh, Kh + nch*K2) of the layer input
-        {
+        // the structurally zero slot tiles of the rows are left unwritten when the layer's kernel never uses them: the low-rank
+        // layer 1 and the float64 dense layers (every pair-mean k-step under the tile masks)
+        auto pm_skip_of = [&](int ll) {
+            if (dr || !s->use_pm_skip || ll < 1) return 0;
+            const int Kh_l = S.h1[ll], K2_l = S.h2[ll], Kloc_l = Kh_l + S.nch * K2_l;
+            // (the chunked kernels of ds_wide.h have no masks: what they take over keeps every slot)
+            const bool wide_lr = wide && (s->wide_all || (sizeof(T) == 8 && lr_nc <= 2)), wide_gemm = wide && (s->wide_all || sizeof(T) == 8);
+            if (lr_on && ll == 1) return wide_lr ? 0 : 1;
+            return (s->res1[ll] && Kloc_l % 16 == 0 && Kh_l % 16 == 0 && K2_l % 16 == 0 && !int8_layer(s, ll) && !wide_gemm && ds::pm_instance<T>(ST)) ? 1 : 0;
+        };
+        if (!expanded) {
             ProfScope ps(s, DS_PROF_M2_EXPAND, st);
             const bool xl = lr_on && l == 0;
-            // the structurally zero slot tiles of the rows are left unwritten when this layer's kernel never uses them: the low-rank
-            // layer 1 and the float64 dense layers (every pair-mean k-step under the tile masks)
-            int skip = 0;
-            if (!dr && s->use_pm_skip && l >= 1) {
-                const int Kloc_l = Kh + S.nch * K2;
-                // (the chunked kernels of ds_wide.h have no masks: what they take over keeps every slot)
-                const bool wide_lr = wide && (s->wide_all || (sizeof(T) == 8 && lr_nc <= 2)), wide_gemm = wide && (s->wide_all || sizeof(T) == 8);
-                if (lr_on && l == 1) skip = wide_lr ? 0 : 1;
-                else if (s->res1[l] && Kloc_l % 16 == 0 && Kh % 16 == 0 && K2 % 16 == 0 && !int8_layer(s, l) && !wide_gemm && ds::pm_instance<T>(ST))
-                    skip = 1;
-            }
             hipLaunchKernelGGL((ds::k_m2_expand<T>), dim3(S.N, (unsigned)Bc, m2_split<T>(K2, S.N)), dim3(256), (size_t)(K2 * 5 * S.N + S.nch * K2 * 5) / m2_split<T>(K2, S.N) * sizeof(T), st, S,
-                               c.H2[hi], K2, xl ? c.XL : c.G[gi], Kh, xl ? K0loc : S.ldk, skip);
+                               c.H2[hi], K2, xl ? c.XL : c.G[gi], Kh, xl ? K0loc : S.ldk, pm_skip_of(l));
         }
+        expanded = false;
         if (stop == STOP_G0 + l) return copy_out(dr, c.G[gi], L.G * Bc, st);
         // pair stream layer
         if (l < S.n_double) {
@@ -519,10 +521,28 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             const bool res = s->res2[l] && !res_sep;
             const T* W2 = blk(s->i_w2[l]); const T* b2 = blk(s->i_b2[l]);
             ProfScope ps(s, DS_PROF_TWO_LAYER, st);
+            // the layer and the spin means of its output in one kernel (k_two_layer_expand: a workgroup per electron) when the output jets
+            // of an electron's pairs fit the LDS: the next level's rows land in the buffer the one-electron layer below writes its output to
+            const unsigned xz = (!res && K2o == 32) ? 2 : 1;       // feature splits (a residual layer keeps its operands: all features in one workgroup)
+            // (the output itself has a reader only if another pair layer or the orbital head's pair means follow)
+            T* Hnext = (l + 1 < S.n_double || s->use_last) ? c.H2[hi ^ 1] : nullptr;
+            // electrons per workgroup: two where the output is written and a single electron's pairs would end in the middle of a 128-byte line
+            const int EW = (Hnext && S.N % 16 == 8 && xz == 2) ? 2 : 1, NW = (EW * S.N + 15) / 16;
+            const size_t xlds = ((size_t)(K2o / xz) * 5 * EW * S.N + (size_t)EW * S.nch * (K2o / xz) * 5) * sizeof(T);
+            if (!dr && s->use_pair_expand && !res_sep && l + 1 < S.n_layers && NW <= 8 && xlds <= 150 * 1024) {
+#define DS_TWOX(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer_expand<T, NT2, RES>), dim3(S.N / EW, (unsigned)Bc, xz), dim3(64 * NW), xlds, st, S, c.H2[hi], K2, W2, b2, Hnext, \
+                                             c.G[gi ^ 1], S.h1[l + 1], S.ldk, pm_skip_of(l + 1), EW)
+                if (K2o == 32 && res) DS_TWOX(2, true);
+                else if (res) DS_TWOX(1, true);
+                else DS_TWOX(1, false);
+#undef DS_TWOX
+                expanded = true;
+            } else {
 #define DS_TWO(NT2, RES) hipLaunchKernelGGL((ds::k_two_layer<T, NT2, RES, false>), grid, dim3(256), 0, st, S, c.H2[hi], K2, W2, b2, c.H2[hi ^ 1])
             if (K2o == 32) { if (res) DS_TWO(2, true); else DS_TWO(2, false); }
             else { if (res) DS_TWO(1, true); else DS_TWO(1, false); }
 #undef DS_TWO
+            }
             if (res_sep)
                 hipLaunchKernelGGL((ds::k_pair_res_add<T>), dim3((unsigned)(((size_t)K2o * 5 * S.NP + 255) / 256), (unsigned)Bc), dim3(256), 0, st, c.H2[hi], K2, c.H2[hi ^ 1], K2o,
                                    S.nf, S.NP);
@@ -1589,6 +1609,7 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
     s->no_lu_wave = getenv("DS_NO_LU_WAVE") != nullptr;
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
     s->use_pm_skip = getenv("DS_NO_PM_SKIP") == nullptr;
+    s->use_pair_expand = getenv("DS_NO_PAIR_EXPAND") == nullptr;
     s->use_i8 = getenv("DS_I8") != nullptr && getenv("DS_NO_I8") == nullptr;
     s->use_ldsb = getenv("DS_NO_LDSB") == nullptr;
     s->use_pair_fuse = getenv("DS_NO_PAIR_FUSE") == nullptr;

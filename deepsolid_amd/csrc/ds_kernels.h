@@ -399,6 +399,126 @@ __global__ void __launch_bounds__(256, ((RES && !VAL && sizeof(T) == 8 && NT2 ==
     }
 }
 
+// 2c. (round 6) pair layer + the spin means of its OUTPUT in one kernel (energy chain): k_two_layer followed by k_m2_expand of the
+// next level read the layer's output back from memory (4.1 GB per 4096 bcc-Li walkers) -- and the last pair layer's output has no
+// other reader at all.  Here a workgroup owns the EW * N pairs of EW consecutive electrons (one wave per 16 of them, the last one
+// possibly partly idle: the products are a small part of this kernel), runs the layer exactly like k_two_layer, leaves the output jets in LDS and expands them
+// into the pair-mean rows of the next one-electron layer exactly like k_m2_expand (same sums in the same order: bit-identical rows).
+// Hout == nullptr: nobody reads the layer output itself.  grid (N / EW, walkers, feature splits), block 64 * ceil(EW * N / 16),
+// LDS (Kout * 5 * EW * N + EW * nch * Kout * 5) * sizeof(T) with Kout = 16 NT2 the features of ONE split: a layer without residual (layer 0:
+// a handful of input features) runs its 32 output features as two workgroups of 16 -- half the LDS, twice the workgroups in flight
+// for a kernel whose phases (load, products, tanh, sums, expand) follow each other behind barriers.  EW = 2 where the layer output is
+// written and N is an odd multiple of 8: a workgroup's stretch of every output row then begins and ends on a 128-byte line (with one
+// electron per workgroup neighbouring workgroups -- on different XCDs -- each wrote part of a line).
+template <typename T, int NT2, bool RES>
+__global__ void __launch_bounds__(512) k_two_layer_expand(SysDev<T> S, const T* __restrict__ Hin, int Kin, const T* __restrict__ W,
+                                                          const T* __restrict__ bias, T* __restrict__ Hout, T* __restrict__ G, int row0,
+                                                          int ldg, int skip, int EW) {
+    typedef typename Acc4<T>::type acc_t;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int w = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x, nt = blockDim.x;
+    const int N = S.N, NP = S.NP, P = S.P, Kout = 16 * NT2, e0 = blockIdx.x * EW, PW = EW * N;
+    const int KT = Kout * gridDim.z, n0 = Kout * blockIdx.z;      // all output features of the layer; this workgroup's first one
+    const int lr = lane & 15, lq = lane >> 4;
+    const bool valid = wave * 16 + lr < PW;
+    const int pl = valid ? wave * 16 + lr : PW - 1;              // (idle lanes load the last pair again and store nothing)
+    const T* Hw = Hin + (size_t)w * Kin * 5 * NP + e0 * N + pl;
+    T* hs = reinterpret_cast<T*>(smem_raw);     // [Kout * 5][PW]  output jets of the workgroup's pairs
+    T* sums = hs + Kout * 5 * PW;               // [EW][nch][Kout][5]
+    acc_t acc[NT2][5];
+#pragma unroll
+    for (int a = 0; a < NT2; ++a)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc[a][c] = acc_t{0, 0, 0, 0};
+    constexpr bool KEEP = RES && sizeof(T) == 8;       // (see k_two_layer: the residual is the operand the lane loaded)
+    T bk[KEEP ? 4 * NT2 : 1][5];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int ks = 0; ks < 4 * NT2; ++ks)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) bk[ks][c] = Hw[(size_t)((4 * ks + lq) * 5 + c) * NP];
+#pragma unroll
+        for (int ks = 0; ks < 4 * NT2; ++ks) {
+            T av[NT2];
+#pragma unroll
+            for (int a = 0; a < NT2; ++a) av[a] = W[(size_t)(4 * ks + lq) * KT + n0 + 16 * a + lr];
+#pragma unroll
+            for (int a = 0; a < NT2; ++a)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) acc[a][c] = mfma16(av[a], bk[ks][c], acc[a][c]);
+        }
+    } else
+    for (int ks = 0; ks < Kin / 4; ++ks) {
+        T av[NT2], bv[5];
+#pragma unroll
+        for (int a = 0; a < NT2; ++a) av[a] = W[(size_t)(4 * ks + lq) * KT + n0 + 16 * a + lr];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) bv[c] = Hw[(size_t)((4 * ks + lq) * 5 + c) * NP];
+#pragma unroll
+        for (int a = 0; a < NT2; ++a)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[a][c] = mfma16(av[a], bv[c], acc[a][c]);
+    }
+    const T rs2 = T(0.70710678118654752440);
+    T* Ho = (Hout && valid) ? Hout + ((size_t)w * KT + n0) * 5 * NP + e0 * N + pl : nullptr;
+#pragma unroll
+    for (int a = 0; a < NT2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 16 * a + acc_row<T>(lane, r);
+            const T z0 = acc[a][0][r] + bias[n0 + n];
+            const T y = ds_tanh(z0), d1 = 1 - y * y, d2 = -2 * y * d1;
+            const T z1 = acc[a][1][r], z2 = acc[a][2][r], z3 = acc[a][3][r], z4 = acc[a][4][r];
+            const T o[5] = {y, d1 * z1, d1 * z2, d1 * z3, d1 * z4 + d2 * 2 * (z1 * z1 + z2 * z2 + z3 * z3)};
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                T v = o[c];
+                if (RES) v = ((KEEP ? bk[KEEP ? 4 * a + r : 0][c] : Hw[(size_t)(n * 5 + c) * NP]) + v) * rs2;
+                if (Ho) Ho[(size_t)(n * 5 + c) * NP] = v;
+                if (valid) hs[(n * 5 + c) * PW + pl] = v;
+            }
+        }
+    __syncthreads();
+    const int nch = S.nch;
+    for (int idx = tid; idx < EW * nch * Kout * 5; idx += nt) {
+        const int kc = idx % (5 * Kout), es = idx / (5 * Kout), s = es % nch, el = es / nch;
+        const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
+        T v = 0;
+        for (int j = j0; j < j0 + ns; ++j) v += hs[kc * PW + el * N + j];
+        sums[idx] = v / T(ns);
+    }
+    __syncthreads();
+    // (a thread per four consecutive slots of one row, rows walked in index order: a per-lane slot descriptor with two rows per
+    //  wave pass measured slower, EXPERIMENTS.md)
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    const int QP = P / 4;
+    for (int idx = tid; idx < EW * nch * Kout * QP; idx += nt) {
+        const int row = idx / QP, sq = idx - row * QP, k = row % Kout, es = row / Kout, s = es % nch, el = es / nch, e = e0 + el;
+        const int j0 = s == 0 ? 0 : S.n_up, ns = s == 0 ? S.n_up : S.n_dn;
+        if (skip) {
+            const int t = sq >> 2, lo = (2 + 3 * j0) >> 4, hi = (4 + 3 * (j0 + ns - 1)) >> 4;
+            if (!(t == 0 || t == ((2 + 3 * e) >> 4) || t == ((4 + 3 * e) >> 4) || (t >= lo && t <= hi))) continue;
+        }
+        const T inv = T(1) / T(ns);
+        const T* sm = sums + (es * Kout + k) * 5;
+        vec4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int slot = 4 * sq + u;
+            T x = 0;
+            if (slot == 0) x = sm[0];
+            else if (slot == 1) x = sm[4];
+            else if (slot < S.D) {
+                const int j = (slot - 2) / 3, c = (slot - 2) - 3 * j;
+                if (j == e) x = -sm[1 + c];
+                else if (j >= j0 && j < j0 + ns) x = hs[(k * 5 + 1 + c) * PW + el * N + j] * inv;
+            }
+            v[u] = x;
+        }
+        *reinterpret_cast<vec4*>(G + ((size_t)(w * N + e) * ldg + row0 + s * KT + n0 + k) * P + 4 * sq) = v;
+    }
+}
+
 // rows [row0, row0 + nch*K2) of G (value chain) from the per-tile segment sums of k_two_layer: mean over the partners j of
 // spin s of h2[j][e] = (sum over the tiles that meet segment (e, s), in tile order) / n_s.   grid (N, groups), block 256.
 // Reads walk (feature, column-in-5) fastest -- contiguous in PARTM --, the result is transposed through LDS so that the

@@ -359,6 +359,35 @@ def test_dense_layer_skips_the_zero_tiles_of_its_pair_mean_rows(no_lowrank, monk
     assert np.array_equal(out[None], out['1'])
 
 
+@pytest.mark.parametrize('name', ['bcc_li', 'lih', 'li_polarized', 'lih_lastlayer', 'lih_narrow', 'graphene', 'diamond'])
+def test_pair_layer_writes_the_pair_means_of_the_next_layer(name, monkeypatch):
+    """Round 6: a pair layer of the energy chain leaves its output jets in LDS and writes the pair-mean rows of the NEXT
+    one-electron layer itself (k_two_layer_expand: network.py:525-528 followed by :305-332, one workgroup per electron; the last
+    pair layer's output is not written at all when nothing else reads it).  Same sums in the same order as k_m2_expand: with
+    DS_NO_PAIR_EXPAND=1 (k_two_layer, then k_m2_expand reading the output back) the energies must be IDENTICAL to the last bit,
+    and both reproduce the reference-executed kinetic energies.  Cases: 24 pairs per electron in two waves (bcc-Li), a partly
+    idle single wave (LiH), unequal spins, the orbital head reading the last pair layer (use_last_layer), 16-wide pair layers,
+    48 and 96 electrons."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = dev_params(params)
+    nw = min(2 if name == 'diamond' else 4, len(fx['ke_ref']))
+    x = torch.as_tensor(fx['x'][:nw], device='cuda')
+    monkeypatch.delenv('DS_I8', raising=False)
+    out = {}
+    for flag in (None, '1'):
+        if flag:
+            monkeypatch.setenv('DS_NO_PAIR_EXPAND', flag)
+        else:
+            monkeypatch.delenv('DS_NO_PAIR_EXPAND', raising=False)
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
+        out[flag] = torch.view_as_complex(sysd.local_energy(dp, x)[0]).cpu().numpy()
+        for b in range(nw):
+            assert abs(out[flag][b] - fx['ke_ref'][b]) < 1e-9 * max(1.0, abs(fx['ke_ref'][b])), (flag, b, out[flag][b], fx['ke_ref'][b])
+    assert np.array_equal(out[None], out['1'])
+
+
 @pytest.mark.parametrize('no_lowrank', [False, True])
 def test_int8_split_hidden_layer_vs_float64_kernel(no_lowrank, monkeypatch):
     """The dense residual hidden layers of the 5-slot-tile float64 cells (bcc-Li 2x2x2: layer 2; with DS_NO_LOWRANK=1 layers 1 and 2)
