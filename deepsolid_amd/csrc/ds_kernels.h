@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(512) k_two_layer_expand(SysDev<T> S, const T* 
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
                 T v = o[c];
-                if (RES) v = ((KEEP ? bk[KEEP ? 4 * a + r : 0][c] : Hw[(size_t)(n * 5 + c) * NP]) + v) * rs2;
+                if (RES) v = ((KEEP ? bk[KEEP ? 4 * a + r : 0][c] : Hw[(size_t)((n0 + n) * 5 + c) * NP]) + v) * rs2;
                 if (Ho) Ho[(size_t)(n * 5 + c) * NP] = v;
                 if (valid) hs[(n * 5 + c) * PW + pl] = v;
             }
