@@ -388,6 +388,28 @@ def test_pair_layer_writes_the_pair_means_of_the_next_layer(name, monkeypatch):
     assert np.array_equal(out[None], out['1'])
 
 
+@pytest.mark.parametrize('name', ['lih', 'bcc_li', 'diamond'])
+def test_pair_layer_writes_the_pair_means_of_the_next_layer_float32(name, monkeypatch):
+    """The float32 instances of k_two_layer_expand (no kept operands: the residual is read again) against the two-kernel path:
+    identical float32 energies, to the last bit."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case(name)
+    dp = {k: [{kk: torch.as_tensor(vv, dtype=torch.float32, device='cuda') for kk, vv in d.items()} for d in v] for k, v in params.items()}
+    nw = min(2, len(fx['x']))
+    x = torch.as_tensor(fx['x'][:nw], dtype=torch.float32, device='cuda')
+    out = {}
+    for flag in (None, '1'):
+        if flag:
+            monkeypatch.setenv('DS_NO_PAIR_EXPAND', flag)
+        else:
+            monkeypatch.delenv('DS_NO_PAIR_EXPAND', raising=False)
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float32)
+        out[flag] = sysd.local_energy(dp, x)[0].cpu().numpy()
+    assert np.isfinite(out[None]).all()
+    assert np.array_equal(out[None], out['1'])
+
+
 @pytest.mark.parametrize('no_lowrank', [False, True])
 def test_int8_split_hidden_layer_vs_float64_kernel(no_lowrank, monkeypatch):
     """The dense residual hidden layers of the 5-slot-tile float64 cells (bcc-Li 2x2x2: layer 2; with DS_NO_LOWRANK=1 layers 1 and 2)
