@@ -101,6 +101,7 @@ struct ds_system {
     int val_nb = 0;                   // DS_VAL_NB = 1 / 2 / 4: one wave-tile width for the value chain's GEMMs (default: by workgroup count)
     bool det_valu = false;            // DS_DET_VALU (read once in ds_system_create): VALU determinant-trace kernel
     int64_t chunk_cap = 4096;         // DS_CHUNK_WALKERS: walkers per chunk of the local-energy chain (workspace sizing)
+    bool use_g4 = true;               // DS_NO_G4 unset: the dense float64 layer of the 24-electron cells multiplies its last slot tile as 4-column groups
     bool use_pair_expand = true;      // DS_NO_PAIR_EXPAND unset: a pair layer writes the pair-mean rows of the next one-electron layer itself (k_two_layer_expand)
     bool use_pm_skip = true;          // DS_NO_PM_SKIP unset: the dense float64 hidden layer skips the structurally zero slot tiles of its pair-mean rows
     bool use_lr = true;               // DS_NO_LOWRANK unset: the first hidden layer runs on the low-rank form of its input (k_layer1_lr)
@@ -628,6 +629,8 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 ga.oe.dbg = s->dbg & 3;                 // (timing experiments: 1 = no epilogue, 2 = accumulators start at zero)
                 // pair-mean rows of a hidden layer: structurally zero slot tiles are skipped (whole rounds of four k-steps per partner spin)
                 if (l > 0 && s->use_pm_skip && Kh % 16 == 0 && K2 % 16 == 0) { ga.oe.pm_k0 = Kh / 4; ga.oe.pm_ks = K2 / 4; ga.oe.pm_nup = S.n_up; ga.oe.pm_nch = S.nch; }
+                // 73 .. 76 jets on five slot tiles (24 electrons): the last tile as three groups of four columns
+                if (s->use_g4 && ST == 5 && S.D > 72 && S.D <= 76) ga.oe.g4 = 3;
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }
                 layer_gemm(2, ga);
             } else {
@@ -1610,6 +1613,7 @@ int ds_system_create(const ds_system_desc* ref_desc, ds_system** out) {
     s->use_lr = getenv("DS_NO_LOWRANK") == nullptr;
     s->use_pm_skip = getenv("DS_NO_PM_SKIP") == nullptr;
     s->use_pair_expand = getenv("DS_NO_PAIR_EXPAND") == nullptr;
+    s->use_g4 = getenv("DS_NO_G4") == nullptr;
     s->use_i8 = getenv("DS_I8") != nullptr && getenv("DS_NO_I8") == nullptr;
     s->use_ldsb = getenv("DS_NO_LDSB") == nullptr;
     s->use_pair_fuse = getenv("DS_NO_PAIR_FUSE") == nullptr;

@@ -47,7 +47,25 @@ template <typename T> struct OrbEpi {
     // partner spin -- are exactly zero outside slot tile 0, the electron's own tile(s) and the tiles of the partners' slots
     // (k_m2_expand writes zeros there): the products on the other tiles are skipped.  pm_ks = 0: no such rows / no skipping
     int pm_k0, pm_ks, pm_nup, pm_nch;
+    // (round 6) > 0: the last slot tile holds at most 4 g4 jets -- the dense 24-electron instance multiplies it as g4 groups of 4 columns
+    // (v_mfma_f64_4x4x4, 17 cycles each) instead of one 16-column tile (64 cycles): k_jet_gemm<.., 2, G4>
+    int g4;
 };
+
+// DPP move inside the 16-lane rows under a bank mask (BANK bit q = quad q of every row is written)
+template <int CTRL, int BANK> __device__ __forceinline__ int dpp_mov(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, BANK, false); }
+// DPP control that brings quad SRC of a row to quad DST: row_shr:4(DST - SRC) / row_shl:4(SRC - DST); the identity quad_perm for SRC == DST
+template <int SRC, int DST> constexpr int quad_ctrl() { return DST == SRC ? 0xE4 : (DST > SRC ? 0x110 + 4 * (DST - SRC) : 0x100 + 4 * (SRC - DST)); }
+// Element r of a 16x16 accumulator tile (feature lq + 4 r, column lr) from the results c[g] of v_mfma_f64_4x4x4 on column group g (lane
+// (lq, lr): feature 4 (lr >> 2) + lq, column 4 g + (lr & 3)): quad g of the row takes c[g] from quad r; columns beyond 4 NG are zero.
+template <int NG, int R> __device__ __forceinline__ double quads_to_tile(const double (&c)[NG]) {
+    int hi = 0, lo = 0;
+    if constexpr (NG > 0) { hi = dpp_mov<quad_ctrl<R, 0>(), 1>(hi, __double2hiint(c[0])); lo = dpp_mov<quad_ctrl<R, 0>(), 1>(lo, __double2loint(c[0])); }
+    if constexpr (NG > 1) { hi = dpp_mov<quad_ctrl<R, 1>(), 2>(hi, __double2hiint(c[1])); lo = dpp_mov<quad_ctrl<R, 1>(), 2>(lo, __double2loint(c[1])); }
+    if constexpr (NG > 2) { hi = dpp_mov<quad_ctrl<R, 2>(), 4>(hi, __double2hiint(c[2])); lo = dpp_mov<quad_ctrl<R, 2>(), 4>(lo, __double2loint(c[2])); }
+    if constexpr (NG > 3) { hi = dpp_mov<quad_ctrl<R, 3>(), 8>(hi, __double2hiint(c[3])); lo = dpp_mov<quad_ctrl<R, 3>(), 8>(lo, __double2loint(c[3])); }
+    return __hiloint2double(hi, lo);
+}
 
 // Residual stash (EPI = 2 / 4): the residual rows of a layer are rows n0..n0+16*NB-1 of the SAME tile the wave streams as
 // its B operand, and the lane that needs X[n][slot] in the epilogue is a lane that held it in its operand registers at
@@ -337,7 +355,7 @@ __device__ __forceinline__ void orbital_epilogue(typename Acc4<T>::type (&acc)[N
 //   EPI = 5: orbital head (network.py:543-557): complex phi from packed columns, M = phi * q (envelope x Bloch
 //            phase 5-jet of the tile's electron) with the product rule, stored into MOUT.
 //   EPI = 8: the same for the value chain (slots = walkers): M = phi * q, values only.
-template <typename T, int NB, int ST, int EPI>
+template <typename T, int NB, int ST, int EPI, int G4 = 0>
 // (very wide slot ranges, ST > 10: four waves per workgroup so that a wave may use the whole register file)
 __global__ void __launch_bounds__((NB == 3 || ST > 5 ? 256 : 1024 / NB), (ST <= 10 ? 2 : 1))
 k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride, const T* __restrict__ W, int K,
@@ -395,6 +413,20 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     acc_t acc[NB][ST];
     // (the dense 24-electron instance adds S in its epilogue: layer_epilogue_sadd)
     constexpr bool SADD = EPI == 2 && NB == 4 && ST == 5 && sizeof(T) == 8 && DS_SADD;
+    static_assert(G4 == 0 || (SADD && G4 <= 4), "column groups on the last slot tile: the float64 <4, 5, 2> instance only");
+    // G4 > 0: the last slot tile as G4 four-column groups.  Their B operand (B_blk[k][j] in lane 16 k + 4 blk + j, the same for every
+    // block) is formed through 512 bytes of LDS per wave -- the stash entries of the last tile's PADDING columns (lanes lr >= 12 of the
+    // first four parked k-steps: zeros, restored behind the loop; the stash fills the workgroup's 80 KB exactly) --: the 16-column
+    // operand of the tile is written as it stands at the start of the k-step and read back as
+    // lane (lq, lr) <- X[k = lq][16 (ST - 1) + 4 g + (lr & 3)] -- LDS instructions, not vector ALU ones (those
+    // take matrix-pipe issue cycles on this part: forming the groups with DPP moves cost what the shorter products saved), and no
+    // younger memory loads in front of the ring's (the load counter completes in order).  Accumulators start at zero (SADD) and are
+    // turned into acc[.][ST - 1] before the epilogue.
+    double c4[G4 ? NB : 1][G4 ? G4 : 1];
+#pragma unroll
+    for (int a = 0; a < (G4 ? NB : 1); ++a)
+#pragma unroll
+        for (int g = 0; g < (G4 ? G4 : 1); ++g) c4[a][g] = 0;
     constexpr int NSF = DS_SADD_NSF;
     T sfull[SADD ? NSF : 1][ST], s0[NB * 4];
     if (LAYER && !SADD && !(EPI == 2 && DS_EXP(oe.dbg & 2))) {
@@ -420,8 +452,11 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     // with no register copies at the loop end (the 4x unrolled body renames the sets).
     constexpr int NSET = ring_sets<T, NB, ST>();
     T av[NSET][NB], bv[NSET][ST];
+    T bg[G4 ? G4 : 1];                      // group operands of the current k-step
+    T* gq = stash + (lq * ST + ST - 1) * 64 + 12 + (lr & 3);      // element (k = lq, column c) at gq[16 (c >> 2)] (c & 3 = lr & 3)
     const T* Wl = Wp + wo;                  // this lane's operands of the next k-step to request
     const T* Xl = Xp + xo;
+
     const size_t wstep = (size_t)4 * Nout, xstep = (size_t)4 * P;
     auto load_set = [&](int u) {
 #pragma unroll
@@ -431,7 +466,23 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         Wl += wstep;
         Xl += xstep;
     };
+    auto load_groups = [&](int u) {
+        if constexpr (G4 > 0) {
+            gq[16 * (lr >> 2)] = bv[u][ST - 1];
+#pragma unroll
+            for (int g = 0; g < G4; ++g) bg[g] = gq[16 * g];
+        }
+    };
+    auto last_tile = [&](int u) {
+        if constexpr (G4 > 0) {
+#pragma unroll
+            for (int g = 0; g < G4; ++g)
+#pragma unroll
+                for (int a = 0; a < NB; ++a) c4[a][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u][a], bg[g], c4[a][g], 0, 0, 0);
+        }
+    };
     auto step = [&](int u, int k) {
+        load_groups(u);
         if (NA > 0) {                    // k-steps n0/4 .. n0/4 + 4*NA - 1 carry this wave's residual rows: park the operands
             const int j = k - (n0 >> 2);
             if (j >= 0 && j < 4 * NA) {
@@ -442,15 +493,20 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
 #pragma unroll
         for (int a = 0; a < NB; ++a)
 #pragma unroll
-            for (int s = 0; s < ST; ++s) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
+            for (int s = 0; s < (G4 ? ST - 1 : ST); ++s) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
+        last_tile(u);
     };
     // (pair-mean rows: a k-step under a wave-uniform slot-tile mask; bit-identical, the skipped products add exact zeros)
     auto step_m = [&](int u, unsigned m) {
+        load_groups(u);
 #pragma unroll
         for (int s = 0; s < ST; ++s)
             if ((m >> s) & 1) {
+                if (G4 > 0 && s == ST - 1) last_tile(u);
+                else {
 #pragma unroll
-                for (int a = 0; a < NB; ++a) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
+                    for (int a = 0; a < NB; ++a) acc[a][s] = mfma16(av[u][a], bv[u][s], acc[a][s]);
+                }
             }
     };
     auto park = [&](int u, int k) {      // (the residual parking of `step`, for the masked rounds that straddle pm_k0)
@@ -566,6 +622,18 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
             for (int ks = 0; ks < nks; ++ks) { load_set(0); step_m(0, pm_k0 < nks ? (ks < pm_k0 ? own0 : pm_mask(ks)) : ~0u); }
         } else {
             for (int ks = 0; ks < nks; ++ks) { load_set(0); step(0, ks); }
+        }
+    }
+    if constexpr (G4 > 0) {
+        static_assert(G4 == 0 || NA >= 1, "the group staging lives in the first parked block of the stash");
+        gq[16 * (lr >> 2)] = T(0);              // (the padding columns of the parked rows are zeros again)
+        // the column groups back into the accumulator layout of a 16-column tile (DPP inside the 16-lane rows): the epilogue is unchanged
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+            acc[a][ST - 1][0] = quads_to_tile<G4, 0>(c4[a]);
+            acc[a][ST - 1][1] = quads_to_tile<G4, 1>(c4[a]);
+            acc[a][ST - 1][2] = quads_to_tile<G4, 2>(c4[a]);
+            acc[a][ST - 1][3] = quads_to_tile<G4, 3>(c4[a]);
         }
     }
     stamp();

@@ -32,7 +32,17 @@ template <typename T, int NB, int ST> struct TileImpl {
                                         a.n_tiles, a.Z, a.zws, a.zts, a.Nout, a.P, a.Sb, a.bias, a.oe)
         switch (epi) {
             case 1: DS_G(1, 0); break;
-            case 2: DS_G(2, (gemm_stash_bytes<T, NB, ST>(block.x))); break;
+            case 2:
+                if constexpr (NB == 4 && ST == 5 && sizeof(T) == 8) {
+                    // (the last slot tile as three groups of four columns: 74 jets of the 24-electron cells)
+                    if (a.oe.g4 == 3) {
+                        hipLaunchKernelGGL((k_jet_gemm<T, NB, ST, 2, 3>), grid, block, (gemm_stash_bytes<T, NB, ST>(block.x)), st, a.X, a.xws, a.xts, a.W, a.K, a.X2, a.x2ws,
+                                           a.W2, a.K2, a.n_tiles, a.Z, a.zws, a.zts, a.Nout, a.P, a.Sb, a.bias, a.oe);
+                        break;
+                    }
+                }
+                DS_G(2, (gemm_stash_bytes<T, NB, ST>(block.x)));
+                break;
             case 5: DS_G(5, 0); break;
             case 6: DS_G(6, 0); break;
             case 9: DS_G(9, 0); break;

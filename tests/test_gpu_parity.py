@@ -388,6 +388,38 @@ def test_pair_layer_writes_the_pair_means_of_the_next_layer(name, monkeypatch):
     assert np.array_equal(out[None], out['1'])
 
 
+@pytest.mark.parametrize('no_lowrank', [False, True])
+def test_dense_layer_multiplies_its_last_slot_tile_as_four_column_groups(no_lowrank, monkeypatch):
+    """Round 6: 24 electrons have 74 jets on five 16-column slot tiles; k_jet_gemm<double,4,5,2,G4=3> multiplies the last tile as
+    three groups of four columns (v_mfma_f64_4x4x4, 17 cycles each) instead of one 16-column tile (64 cycles) and turns the group
+    accumulators back into the tile layout in front of the unchanged epilogue.  The two instruction shapes need not round alike:
+    against DS_NO_G4=1 (16-column products throughout) the energies agree to 1e-12 relative, both reproduce the reference-executed
+    kinetic energies (the padding columns of the layer output stay exactly zero: test_stages_vs_forward_laplacian_oracle[bcc_li]
+    runs this path); with DS_NO_LOWRANK=1 layers 1 and 2 run the kernel."""
+    from deepsolid_amd.device import DeviceSystem
+    from deepsolid_amd.ewaldsum import EwaldTables
+    fx, cell, klist, net_kw, params = load_case('bcc_li')
+    dp = dev_params(params)
+    nw = min(4, len(fx['ke_ref']))
+    x = torch.as_tensor(fx['x'][:nw], device='cuda')
+    monkeypatch.delenv('DS_I8', raising=False)
+    if no_lowrank:
+        monkeypatch.setenv('DS_NO_LOWRANK', '1')
+    else:
+        monkeypatch.delenv('DS_NO_LOWRANK', raising=False)
+    out = {}
+    for flag in (None, '1'):
+        if flag:
+            monkeypatch.setenv('DS_NO_G4', flag)
+        else:
+            monkeypatch.delenv('DS_NO_G4', raising=False)
+        sysd = DeviceSystem(cell, klist, net_kw, EwaldTables(cell), torch.float64)
+        out[flag] = torch.view_as_complex(sysd.local_energy(dp, x)[0]).cpu().numpy()
+        for b in range(nw):
+            assert abs(out[flag][b] - fx['ke_ref'][b]) < 1e-9 * max(1.0, abs(fx['ke_ref'][b])), (flag, b, out[flag][b], fx['ke_ref'][b])
+    assert np.all(np.abs(out[None] - out['1']) <= 1e-12 * np.maximum(1.0, np.abs(out['1']))), np.abs(out[None] - out['1']).max()
+
+
 @pytest.mark.parametrize('name', ['lih', 'bcc_li', 'diamond'])
 def test_pair_layer_writes_the_pair_means_of_the_next_layer_float32(name, monkeypatch):
     """The float32 instances of k_two_layer_expand (no kept operands: the residual is read again) against the two-kernel path:
