@@ -668,8 +668,9 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             }
             ProfScope ps(s, DS_PROF_ORBITAL, st);
             const int ch = S.mat_ch[sp];
-            const ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
-                                   S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
+            ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
+                             S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
+            if (s->use_g4 && ST == 5 && S.D > 72 && S.D <= 76) oe.g4 = 3;      // (48-column float64 waves: the last slot tile as three 4-column groups)
             const ds::GemmArgs<T> ga{c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P, blk(s->i_worb[sp]), Korb,
                                      nullptr, 0, nullptr, 0, ns, nullptr, 0, 0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, nullptr, oe};
             // 192 columns (n_s*K = 96) would give 3 waves of 64 columns per workgroup and leave SIMDs with a single wave;

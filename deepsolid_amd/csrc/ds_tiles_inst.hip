@@ -51,6 +51,14 @@ template <typename T, int NB, int ST> struct TileImpl {
 #undef DS_G
     }
     static void gemm_orb3(dim3 grid, dim3 block, hipStream_t st, const GemmArgs<T>& a) {
+        if constexpr (ST == 5 && sizeof(T) == 8) {
+            // (the last slot tile as three groups of four columns, re-laid through 512 bytes of LDS per wave)
+            if (a.oe.g4 == 3) {
+                hipLaunchKernelGGL((k_jet_gemm<T, 3, ST, 5, 3>), grid, block, (block.x / 64) * 64 * sizeof(T), st, a.X, a.xws, a.xts, a.W, a.K, a.X2, a.x2ws, a.W2, a.K2,
+                                   a.n_tiles, a.Z, a.zws, a.zts, a.Nout, a.P, a.Sb, a.bias, a.oe);
+                return;
+            }
+        }
         if constexpr (ST <= 5)
             hipLaunchKernelGGL((k_jet_gemm<T, 3, ST, 5>), grid, block, 0, st, a.X, a.xws, a.xts, a.W, a.K, a.X2, a.x2ws, a.W2, a.K2, a.n_tiles, a.Z,
                                a.zws, a.zts, a.Nout, a.P, a.Sb, a.bias, a.oe);

@@ -392,7 +392,8 @@ def test_pair_layer_writes_the_pair_means_of_the_next_layer(name, monkeypatch):
 def test_dense_layer_multiplies_its_last_slot_tile_as_four_column_groups(no_lowrank, monkeypatch):
     """Round 6: 24 electrons have 74 jets on five 16-column slot tiles; k_jet_gemm<double,4,5,2,G4=3> multiplies the last tile as
     three groups of four columns (v_mfma_f64_4x4x4, 17 cycles each) instead of one 16-column tile (64 cycles) and turns the group
-    accumulators back into the tile layout in front of the unchanged epilogue.  The two instruction shapes need not round alike:
+    accumulators back into the tile layout in front of the unchanged epilogue; so does the orbital head k_jet_gemm<double,3,5,5,3>
+    (operands re-laid through 512 bytes of LDS per wave).  The two instruction shapes need not round alike:
     against DS_NO_G4=1 (16-column products throughout) the energies agree to 1e-12 relative, both reproduce the reference-executed
     kinetic energies (the padding columns of the layer output stay exactly zero: test_stages_vs_forward_laplacian_oracle[bcc_li]
     runs this path); with DS_NO_LOWRANK=1 layers 1 and 2 run the kernel."""
