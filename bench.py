@@ -84,6 +84,10 @@ def gemm_instance(n_elec, dtype, epi):
     tname = 'double' if dtype == torch.float64 else 'float'
     if epi == 5 and st > 10 and dtype == torch.float32 and not os.environ.get('DS_NO_LDSB'):
         return f'k_jet_gemm_lb<float,{st},5,4>', 1, st            # orbital head of the wide float32 cells: jet rows staged in LDS (ds_ldsb.h)
+    # 73 .. 76 jets on five slot tiles (24 electrons), float64: the last slot tile as three 4-column groups (k_jet_gemm<.., G4 = 3>:
+    # the dense residual layer <4,5,2,3> and the 48-column orbital head <3,5,5,3>; ds_api.hip, DS_NO_G4=1 switches it off)
+    if st == 5 and dtype == torch.float64 and 72 < 3 * n_elec + 2 <= 76 and epi in (2, 5) and not os.environ.get('DS_NO_G4'):
+        return f'k_jet_gemm<{tname},{nb},{st},{epi},3>', nb, st
     return f'k_jet_gemm<{tname},{nb},{st},{epi}>', nb, st
 
 
@@ -490,7 +494,9 @@ def main():
     oc = (2 * cell.nelec[0] * ndet + 63) // 64 * 64                       # packed orbital columns of the spin-up head (ds_api.hip)
     orb_name = gemm_instance(n_e, dtype, 5)[0]
     if nb == 4 and st <= 5 and oc % 256 != 0 and oc % 192 == 0:           # the 48-column-per-wave instance
-        orb_name = orb_name.replace(f',{nb},{st},5>', f',3,{st},5>')
+        orb_name = orb_name.replace(f',{nb},{st},5', f',3,{st},5', 1)
+    else:
+        orb_name = orb_name.replace(',5,3>', ',5>')                      # (the 4-column groups exist for the 48-column instance only)
     # the roofline object describes the kernel with the largest share of the step
     ms_hidden, n_launch = prof['single_hidden']
     flops_total = f_layer * args.batch * n_dense * args.steps            # this rank, timed region (dense hidden layers only)
@@ -545,7 +551,7 @@ def main():
         f_lr = n_e * (2.0 * h1 * h1 * (k0loc + k0sh + 2) + 2.0 * (k0loc + k0sh + nch * h2) * h1 * d_slots + 2.0 * k0loc * h1 * d_slots)
         lr_ms = kms['single_lr']
         lr_ach = f_lr * args.batch / (lr_ms * 1e-3) / 1e12
-        lr_obj = {'bound': 'mfma', 'kernel': gemm_instance(n_e, dtype, 2)[0].replace('k_jet_gemm', 'k_layer1_lr').replace(',2>', ',NC,true,NG>') +
+        lr_obj = {'bound': 'mfma', 'kernel': gemm_instance(n_e, dtype, 2)[0].replace(',2,3>', ',2>').replace('k_jet_gemm', 'k_layer1_lr').replace(',2>', ',NC,true,NG>') +
                   ' (first hidden layer on the rank-%d form of the layer-0 output)' % (k0loc + k0sh),
                   'achieved': lr_ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': lr_ach / peak, 'traffic': None,
                   'flops_per_walker': f_lr, 'dense_layer_flops_per_walker': f_layer,
