@@ -88,6 +88,9 @@ def gemm_instance(n_elec, dtype, epi):
     # the dense residual layer <4,5,2,3> and the 48-column orbital head <3,5,5,3>; ds_api.hip, DS_NO_G4=1 switches it off)
     if st == 5 and dtype == torch.float64 and 72 < 3 * n_elec + 2 <= 76 and epi in (2, 5) and not os.environ.get('DS_NO_G4'):
         return f'k_jet_gemm<{tname},{nb},{st},{epi},3>', nb, st
+    # ... and one group where at most 4 jets sit on the tenth tile (48 electrons: <2,10,2,1>, <2,10,5,1>)
+    if st == 10 and dtype == torch.float64 and 3 * n_elec + 2 - 144 <= 4 and epi in (2, 5) and not os.environ.get('DS_NO_G4'):
+        return f'k_jet_gemm<{tname},{nb},{st},{epi},1>', nb, st
     return f'k_jet_gemm<{tname},{nb},{st},{epi}>', nb, st
 
 

@@ -630,7 +630,11 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
                 // pair-mean rows of a hidden layer: structurally zero slot tiles are skipped (whole rounds of four k-steps per partner spin)
                 if (l > 0 && s->use_pm_skip && Kh % 16 == 0 && K2 % 16 == 0) { ga.oe.pm_k0 = Kh / 4; ga.oe.pm_ks = K2 / 4; ga.oe.pm_nup = S.n_up; ga.oe.pm_nch = S.nch; }
                 // 73 .. 76 jets on five slot tiles (24 electrons): the last tile as three groups of four columns
-                if (s->use_g4 && ST == 5 && S.D > 72 && S.D <= 76) ga.oe.g4 = 3;
+                if (s->use_g4) {
+                    const int used = S.D - 16 * (ST - 1);
+                    if (ST == 5 && used > 8 && used <= 12) ga.oe.g4 = 3;
+                    if (ST == 10 && used <= 4) ga.oe.g4 = 1;          // (48 electrons: two jets on the tenth tile)
+                }
                 if (l > 0 && s->prof_on && (s->prof_only < 0 || s->prof_only == DS_PROF_SINGLE_HIDDEN)) { ga.oe.clk = s->clk_dev; ga.oe.dbg = s->dbg; }
                 layer_gemm(2, ga);
             } else {
@@ -670,7 +674,13 @@ int run_chain(ds_system* s, const T* params, const T* x, int64_t Bc, void* ws, h
             const int ch = S.mat_ch[sp];
             ds::OrbEpi<T> oe{c.Q, c.MOUT, L.MOUT, L.mout_off[ch], S.N, i0, S.nparam[sp], S.nparam_max, S.norb[sp], S.det_n[ch],
                              S.row_off[sp], S.bias_orb ? blk(s->i_borb[sp]) : (const T*)nullptr, nullptr};
-            if (s->use_g4 && ST == 5 && S.D > 72 && S.D <= 76) oe.g4 = 3;      // (48-column float64 waves: the last slot tile as three 4-column groups)
+            // the last slot tile as 4-column groups where at most 12 of its 16 columns are jets (instances: three groups on five tiles -- 24
+            // electrons, the 48-column waves --, one group on ten tiles -- 48 electrons; the launchers fall back to 16-column products)
+            if (s->use_g4) {
+                const int used = S.D - 16 * (ST - 1);
+                if (ST == 5 && used > 8 && used <= 12) oe.g4 = 3;
+                if (ST == 10 && used <= 4) oe.g4 = 1;
+            }
             const ds::GemmArgs<T> ga{c.G[gi] + (size_t)i0 * S.ldk * S.P, (size_t)S.N * S.ldk * S.P, (size_t)S.ldk * S.P, blk(s->i_worb[sp]), Korb,
                                      nullptr, 0, nullptr, 0, ns, nullptr, 0, 0, OC, S.P, s->use_last ? (const T*)c.ZB : (const T*)nullptr, nullptr, oe};
             // 192 columns (n_s*K = 96) would give 3 waves of 64 columns per workgroup and leave SIMDs with a single wave;

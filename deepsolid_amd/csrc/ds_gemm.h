@@ -413,7 +413,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     acc_t acc[NB][ST];
     // (the dense 24-electron instance adds S in its epilogue: layer_epilogue_sadd)
     constexpr bool SADD = EPI == 2 && NB == 4 && ST == 5 && sizeof(T) == 8 && DS_SADD;
-    static_assert(G4 == 0 || ((SADD || (EPI == 5 && sizeof(T) == 8)) && G4 <= 4), "column groups on the last slot tile: the float64 <4, 5, 2> layer and the float64 orbital head (accumulators that start at zero)");
+    static_assert(G4 == 0 || ((EPI == 2 || EPI == 5) && sizeof(T) == 8 && G4 <= 3), "column groups on the last slot tile: float64 residual layers and orbital heads, at most 12 jets on that tile");
     // G4 > 0: the last slot tile as G4 four-column groups.  Their B operand (B_blk[k][j] in lane 16 k + 4 blk + j, the same for every
     // block) is formed through 512 bytes of LDS per wave -- the stash entries of the last tile's PADDING columns (lanes lr >= 12 of the
     // first four parked k-steps: zeros, restored behind the loop; the stash fills the workgroup's 80 KB exactly) --: the 16-column
@@ -429,6 +429,14 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         for (int g = 0; g < (G4 ? G4 : 1); ++g) c4[a][g] = 0;
     constexpr int NSF = DS_SADD_NSF;
     T sfull[SADD ? NSF : 1][ST], s0[NB * 4];
+    if constexpr (G4 > 0 && LAYER && !SADD) {
+        // (the group accumulators start at the shared term too: lane (lq, lr) holds feature 4 (lr >> 2) + lq, column 4 g + (lr & 3))
+        const T* Sg = Sb + ((size_t)w * Nout + n0 + 4 * (lr >> 2) + lq) * P + 16 * (ST - 1) + (lr & 3);
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int g = 0; g < G4; ++g) c4[a][g] = Sg[(size_t)16 * a * P + 4 * g];
+    }
     if (LAYER && !SADD && !(EPI == 2 && DS_EXP(oe.dbg & 2))) {
         // z = W x + (S + b): the accumulators start at the shared spin-mean term, which already carries the bias
         // (EPI = 6 / 7 below, k_shared_term); these loads overlap the first operand loads
@@ -454,8 +462,9 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
     T av[NSET][NB], bv[NSET][ST];
     T bg[G4 ? G4 : 1];                      // group operands of the current k-step
     // element (k = lq, column c) at gq[GQS (c >> 2)] (c & 3 = lr & 3); the orbital head (no stash) has 512 bytes per wave of its own
-    constexpr int GQS = RESID ? 16 : 4;
-    T* gq = RESID ? stash + (lq * ST + ST - 1) * 64 + 12 + (lr & 3) : reinterpret_cast<T*>(gemm_smem) + wave * 64 + lq * 16 + (lr & 3);
+    constexpr bool GQ_STASH = RESID && NA >= 1;      // (instances without a stash have the LDS to themselves: 512 bytes per wave, like the orbital head)
+    constexpr int GQS = GQ_STASH ? 16 : 4;
+    T* gq = GQ_STASH ? stash + (lq * ST + ST - 1) * 64 + 12 + (lr & 3) : reinterpret_cast<T*>(gemm_smem) + wave * 64 + lq * 16 + (lr & 3);
     const T* Wl = Wp + wo;                  // this lane's operands of the next k-step to request
     const T* Xl = Xp + xo;
 
@@ -627,8 +636,7 @@ k_jet_gemm(const T* __restrict__ X, size_t x_walker_stride, size_t x_tile_stride
         }
     }
     if constexpr (G4 > 0) {
-        static_assert(G4 == 0 || !RESID || NA >= 1, "the group staging lives in the first parked block of the stash");
-        if constexpr (RESID) gq[GQS * (lr >> 2)] = T(0);              // (the padding columns of the parked rows are zeros again)
+        if constexpr (GQ_STASH) gq[GQS * (lr >> 2)] = T(0);              // (the padding columns of the parked rows are zeros again)
         // the column groups back into the accumulator layout of a 16-column tile (DPP inside the 16-lane rows): the epilogue is unchanged
 #pragma unroll
         for (int a = 0; a < NB; ++a) {

@@ -41,9 +41,27 @@ template <typename T, int NB, int ST> struct TileImpl {
                         break;
                     }
                 }
+                if constexpr (NB == 2 && ST == 10 && sizeof(T) == 8) {
+                    // (48 electrons: one group of four columns on the last slot tile, staged in the stash's padding slots like the <4, 5> instance)
+                    if (a.oe.g4 == 1) {
+                        hipLaunchKernelGGL((k_jet_gemm<T, NB, ST, 2, 1>), grid, block, (gemm_stash_bytes<T, NB, ST>(block.x)), st, a.X, a.xws, a.xts, a.W, a.K, a.X2, a.x2ws, a.W2, a.K2,
+                                           a.n_tiles, a.Z, a.zws, a.zts, a.Nout, a.P, a.Sb, a.bias, a.oe);
+                        break;
+                    }
+                }
                 DS_G(2, (gemm_stash_bytes<T, NB, ST>(block.x)));
                 break;
-            case 5: DS_G(5, 0); break;
+            case 5:
+                if constexpr (ST == 10 && sizeof(T) == 8) {
+                    // (48 electrons: 146 jets, two of them on the last slot tile -- one group of four columns, re-laid through 512 bytes of LDS per wave)
+                    if (a.oe.g4 == 1) {
+                        hipLaunchKernelGGL((k_jet_gemm<T, NB, ST, 5, 1>), grid, block, (block.x / 64) * 64 * sizeof(T), st, a.X, a.xws, a.xts, a.W, a.K, a.X2, a.x2ws, a.W2, a.K2,
+                                           a.n_tiles, a.Z, a.zws, a.zts, a.Nout, a.P, a.Sb, a.bias, a.oe);
+                        break;
+                    }
+                }
+                DS_G(5, 0);
+                break;
             case 6: DS_G(6, 0); break;
             case 9: DS_G(9, 0); break;
             default: break;

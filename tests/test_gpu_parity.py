@@ -388,18 +388,20 @@ def test_pair_layer_writes_the_pair_means_of_the_next_layer(name, monkeypatch):
     assert np.array_equal(out[None], out['1'])
 
 
-@pytest.mark.parametrize('no_lowrank', [False, True])
-def test_dense_layer_multiplies_its_last_slot_tile_as_four_column_groups(no_lowrank, monkeypatch):
+@pytest.mark.parametrize('name,no_lowrank', [('bcc_li', False), ('bcc_li', True), ('graphene', False), ('graphene', True)])
+def test_dense_layer_multiplies_its_last_slot_tile_as_four_column_groups(name, no_lowrank, monkeypatch):
     """Round 6: 24 electrons have 74 jets on five 16-column slot tiles; k_jet_gemm<double,4,5,2,G4=3> multiplies the last tile as
     three groups of four columns (v_mfma_f64_4x4x4, 17 cycles each) instead of one 16-column tile (64 cycles) and turns the group
     accumulators back into the tile layout in front of the unchanged epilogue; so does the orbital head k_jet_gemm<double,3,5,5,3>
-    (operands re-laid through 512 bytes of LDS per wave).  The two instruction shapes need not round alike:
+    (operands re-laid through 512 bytes of LDS per wave); 48 electrons (146 jets on ten tiles, two on the last) run ONE group:
+    k_jet_gemm<double,2,10,2,1> (accumulators start at the shared term, loaded in the group layout) and <double,2,10,5,1>.
+    The two instruction shapes need not round alike:
     against DS_NO_G4=1 (16-column products throughout) the energies agree to 1e-12 relative, both reproduce the reference-executed
     kinetic energies (the padding columns of the layer output stay exactly zero: test_stages_vs_forward_laplacian_oracle[bcc_li]
     runs this path); with DS_NO_LOWRANK=1 layers 1 and 2 run the kernel."""
     from deepsolid_amd.device import DeviceSystem
     from deepsolid_amd.ewaldsum import EwaldTables
-    fx, cell, klist, net_kw, params = load_case('bcc_li')
+    fx, cell, klist, net_kw, params = load_case(name)
     dp = dev_params(params)
     nw = min(4, len(fx['ke_ref']))
     x = torch.as_tensor(fx['x'][:nw], device='cuda')
