@@ -305,13 +305,13 @@ __device__ __forceinline__ void orbital_epilogue(typename Acc4<T>::type (&acc)[N
             Cx<T> fo[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                // slot sl = so + c of this row: pick its slot tile first (st is workgroup-uniform), then ONE cross-lane read
-                const int sl = so + c, st = sl >> 4, src = base | (sl & 15);
-                T re = phi[0].re, im = phi[0].im;
+                // slot sl = so + c of this row: its slot tile st is workgroup-uniform -- a scalar branch around the ONE cross-lane read of
+                // that tile (a select chain over the tiles costs 16 vector-ALU instructions per slot, and those take matrix-pipe issue cycles)
+                const int sl = so + c, st = __builtin_amdgcn_readfirstlane(sl >> 4), src = base | (sl & 15);
+                fo[c] = Cx<T>(T(0), T(0));
 #pragma unroll
-                for (int s = 1; s < ST; ++s)
-                    if (s == st) { re = phi[s].re; im = phi[s].im; }
-                fo[c] = Cx<T>(__shfl(re, src), __shfl(im, src));
+                for (int s = 0; s < ST; ++s)
+                    if (s == st) fo[c] = Cx<T>(__shfl(phi[s].re, src), __shfl(phi[s].im, src));
             }
             const Cx<T> lap = fL * qv + f0 * ql + T(2) * (fo[0] * qg0 + fo[1] * qg1 + fo[2] * qg2);
             if (valid) {
